@@ -1,0 +1,49 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def api_small():
+    return load_golden("api_small")
+
+
+@pytest.fixture(scope="session")
+def api_approx():
+    return load_golden("api_approx")
+
+
+@pytest.fixture(scope="session")
+def internals_small():
+    return load_golden("internals_small")
+
+
+@pytest.fixture(scope="session")
+def regress_asl():
+    return load_golden("regress_asl")
+
+
+def golden_inputs(g):
+    """Rebuild (X csr float64, group_id, n_groups, q) from a golden api_* fixture."""
+    import scipy.sparse as sp
+
+    X = sp.csr_matrix((g["in_data"], g["in_indices"], g["in_indptr"]), shape=tuple(g["in_shape"]))
+    labels = np.array([f"sg^{c}^{r}" for c, r in zip(g["in_cond"], g["in_rep"])])
+    groups = list(g["groups"])
+    gid = np.array([groups.index(l) for l in labels], dtype=np.int32)
+    return X, gid, len(groups), g["in_q"]

@@ -1,0 +1,205 @@
+"""Generate golden fixtures by running the REAL reference (/root/reference/memento) in this container.
+
+Run here only (the reference cannot travel to the GPU box):  python tests/golden/make_golden.py
+Writes small .npz files next to this script.  The reference needs three packages that are absent
+offline and unused on the hot path (patsy, statsmodels, scanpy: SURVEY.md section 8c); empty stub
+packages are created in a temp dir for the duration of this script.  Inputs are synthetic
+(scrna_parameter_estimation_amd.synth) with X as float64 so scipy accumulates in fp64.
+"""
+
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+warnings.simplefilter("ignore")
+
+
+def _stub_pkgs():
+    d = tempfile.mkdtemp(prefix="memento_stubs_")
+    for name, body in {
+        "patsy": "def dmatrix(*a, **k):\n    raise NotImplementedError\n",
+        "scanpy": "",
+        "statsmodels": "",
+        "statsmodels/api": "",
+        "statsmodels/stats": "",
+        "statsmodels/stats/multitest": "def fdrcorrection(*a, **k):\n    raise NotImplementedError\n",
+    }.items():
+        p = os.path.join(d, name)
+        os.makedirs(p, exist_ok=True)
+        with open(os.path.join(p, "__init__.py"), "w") as f:
+            f.write(body)
+    return d
+
+
+sys.path.insert(0, _stub_pkgs())
+sys.path.insert(0, "/root/reference")
+
+import memento  # noqa: E402  (the reference)
+import memento.bootstrap as rboot  # noqa: E402
+import memento.estimator as rest  # noqa: E402
+import memento.hypothesis_test as rht  # noqa: E402
+
+from scrna_parameter_estimation_amd.synth import synth_adata  # noqa: E402
+
+
+def _groups_dict(d, groups):
+    return np.stack([np.asarray(d[g]) for g in groups])
+
+
+def api_case(name, n_cells, n_genes, density, n_cond, n_rep, seed, num_boot, ht_seed, approx, two_d_pairs=0):
+    adata = synth_adata(n_cells, n_genes, density, n_cond, n_rep, seed, dtype=np.float64)
+    inp = dict(
+        indptr=adata.X.indptr.copy(), indices=adata.X.indices.copy(), data=adata.X.data.copy(),
+        shape=np.array(adata.X.shape), cond=adata.obs["cond"].values.copy(), rep=adata.obs["rep"].values.copy(),
+        q=adata.obs["q"].values.copy(), gene_names=np.array(adata.var.index.tolist()),
+    )
+    memento.setup_memento(adata, q_column="q")
+    out = {}
+    m = adata.uns["memento"]
+    out["size_factor"] = adata.obs["memento_size_factor"].values.copy()
+    out["all_q"] = np.float64(m["all_q"])
+    out["all_m"] = m["all_1d_moments"][0].copy()
+    out["all_v"] = m["all_1d_moments"][1].copy()
+    out["least_variable_genes"] = np.array(m["least_variable_genes"])
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    groups = list(m["groups"])
+    out["groups"] = np.array(groups)
+    out["group_q"] = np.array([m["group_q"][g] for g in groups])
+    out["group_ncells"] = np.array([m["group_cells"][g].shape[0] for g in groups])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    out["approx_sf"] = m["all_approx_size_factor"].copy()
+    out["gene_list"] = np.array(m["gene_list"])
+    out["overall_gene_filter"] = m["overall_gene_filter"].copy()
+    out["gene_filter"] = _groups_dict(m["gene_filter"], groups)
+    out["gene_rv_filter"] = _groups_dict(m["gene_rv_filter"], groups)
+    out["mean"] = np.stack([m["1d_moments"][g][0] for g in groups])
+    out["var"] = np.stack([m["1d_moments"][g][1] for g in groups])
+    out["res_var"] = np.stack([m["1d_moments"][g][2] for g in groups])
+    out["mv_regressor"] = np.asarray(m["mv_regressor"][groups[0]]).copy()
+
+    # design: intercept covariate, binary treatment on cond (cond==last vs rest) -- rows follow uns groups
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == n_cond - 1).astype(float)}, index=gdf.index)
+    out["covariate"] = cov.values.copy()
+    out["treatment"] = trt.values.copy()
+
+    np.random.seed(ht_seed)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=num_boot, num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=approx)
+    ht = m["1d_ht"]
+    for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+        out["ht_" + k] = np.asarray(ht[k]).copy()
+    out["ht_seed"] = np.int64(ht_seed)
+    out["num_boot"] = np.int64(num_boot)
+    out["approx"] = np.bool_(approx)
+
+    if two_d_pairs:
+        G = adata.shape[1]
+        rng = np.random.default_rng(seed + 7)
+        i1 = rng.integers(0, G, size=two_d_pairs)
+        i2 = rng.integers(0, G, size=two_d_pairs)
+        i2[0] = i1[0]           # a self pair (skipped by ht_2d, main.py:473)
+        i1[2], i2[2] = i2[1], i1[1]  # a duplicated unordered pair (main.py:476)
+        names = adata.var.index.values
+        pairs = list(zip(names[i1].tolist(), names[i2].tolist()))
+        memento.compute_2d_moments(adata, pairs)
+        out["pair_idx1"] = i1
+        out["pair_idx2"] = i2
+        out["cov2d"] = np.stack([m["2d_moments"][g]["cov"] for g in groups])
+        out["corr2d"] = np.stack([m["2d_moments"][g]["corr"] for g in groups])
+        np.random.seed(ht_seed + 1)
+        memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=num_boot, num_cpus=1, verbose=0,
+                              resampling="bootstrap", approx=approx)
+        for k in ["corr_coef", "corr_se", "corr_asl"]:
+            out["ht2_" + k] = np.asarray(m["2d_ht"][k]).copy()
+        # all-by-all correlation matrix on the first group (estimator.py:236-270)
+        out["corr_matrix_g0"] = memento.get_corr_matrix(adata, groups[0])
+
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{("in_" + k): v for k, v in inp.items()}, **out)
+    print(name, "genes kept", len(out["gene_list"]), "groups", len(groups))
+    return adata
+
+
+def internals_case(name, adata, picks, num_boot, seed):
+    """Per-(gene, group) internals: _unique_expr output order, multinomial weights, replicate moments."""
+    m = adata.uns["memento"]
+    groups = list(m["groups"])
+    est = rest._get_estimator_1d("hyper_relative")
+    out = {}
+    for n, (gi, grp_i) in enumerate(picks):
+        g = groups[grp_i]
+        col = m["group_cells"][g][:, gi]
+        asf = m["approx_size_factor"][g]
+        np.random.seed(seed + n)
+        r = np.random.random(1)
+        r0 = np.random.random()
+        np.random.seed(seed + n)
+        inv_sf, inv_sf_sq, expr, counts = rboot._unique_expr(col, asf)
+        gen = np.random.Generator(np.random.PCG64(5))
+        w = gen.multinomial(col.shape[0], counts / counts.sum(), size=num_boot).T
+        np.random.seed(seed + n)
+        mean, var = rboot._bootstrap_1d(data=col, size_factor=asf, q=m["group_q"][g], _estimator_1d=est, num_boot=num_boot)
+        p = f"p{n}_"
+        out[p + "gene"] = np.int64(gi)
+        out[p + "group"] = np.int64(grp_i)
+        out[p + "r"] = np.float64(r[0])
+        out[p + "r0"] = np.float64(r0)
+        out[p + "inv_sf"] = inv_sf.ravel()
+        out[p + "expr"] = expr.ravel()
+        out[p + "counts"] = counts
+        out[p + "weights"] = w.astype(np.int32)
+        out[p + "mean"] = mean
+        out[p + "var"] = var
+        out[p + "q"] = np.float64(m["group_q"][g])
+        out[p + "n_obs"] = np.int64(col.shape[0])
+    out["n_picks"] = np.int64(len(picks))
+    out["num_boot"] = np.int64(num_boot)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "picks", len(picks))
+
+
+def regress_asl_case(name, seed):
+    """_regress_1d / _cross_coef / _compute_asl golden inputs+outputs (hypothesis_test.py:57-141, 218-300)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    n_rep, B = 8, 400
+    cov = np.column_stack([np.ones(n_rep), rng.normal(size=n_rep)])
+    trt = np.column_stack([(np.arange(n_rep) % 2).astype(float), rng.normal(size=n_rep)])
+    Nc = rng.integers(200, 2000, size=n_rep).astype(float)
+    bm = rng.normal(size=(n_rep, B + 1)) * 0.1 + np.arange(n_rep)[:, None] % 2 * 0.05
+    bv = rng.normal(size=(n_rep, B + 1)) * 0.2
+    bm[:, 17] = np.nan  # a dropped replicate column
+    res = rht._regress_1d(cov, trt, bm.copy(), bv.copy(), Nc, resampling="bootstrap", approx=False)
+    out.update(rg_cov=cov, rg_trt=trt, rg_Nc=Nc, rg_bm=bm, rg_bv=bv)
+    for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], res):
+        out["rg_" + k] = np.asarray(v)
+    # all-ones treatment branch (hypothesis_test.py:262-265)
+    res1 = rht._regress_1d(cov[:, :1], np.ones((n_rep, 1)), bm.copy(), bv.copy(), Nc, resampling="bootstrap", approx=True)
+    for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], res1):
+        out["rg1_" + k] = np.asarray(v)
+    # _compute_asl branches
+    for tag, stat, approx in [("count", 0.05, False), ("tail", 0.45, False), ("approx", 0.3, True), ("negtail", -0.5, False)]:
+        null = rng.normal(size=2000) * 0.12
+        pd_ = np.concatenate([[stat], null + stat])
+        out["asl_in_" + tag] = pd_
+        out["asl_out_" + tag] = np.float64(rht._compute_asl(pd_.copy(), resampling="bootstrap", approx=approx))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: float(out[k]) for k in out if k.startswith("asl_out")})
+
+
+if __name__ == "__main__":
+    ad = api_case("api_small", n_cells=1600, n_genes=120, density=0.12, n_cond=2, n_rep=2, seed=11,
+                  num_boot=300, ht_seed=3, approx=False, two_d_pairs=12)
+    internals_case("internals_small", ad, picks=[(0, 0), (3, 1), (7, 2), (11, 3), (20, 0)], num_boot=64, seed=100)
+    api_case("api_approx", n_cells=2400, n_genes=100, density=0.15, n_cond=2, n_rep=3, seed=23,
+             num_boot=200, ht_seed=5, approx=True)
+    regress_asl_case("regress_asl", seed=5)
