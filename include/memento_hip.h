@@ -1,0 +1,168 @@
+/* memento_hip.h -- C-ABI of libmemento_hip.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * The reference (atarashansky/scrna-parameter-estimation, package `memento`) is pure Python; it has no
+ * FFI.  These entry points are what a ctypes binding inside memento/main.py would call in place of the
+ * numpy/scipy expressions cited on each function (paths relative to /root/reference/).  See
+ * INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *  - every pointer named d_* is a DEVICE pointer (hipMalloc / torch .data_ptr()); h_* is host memory;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on it
+ *    unless stated otherwise; the library never allocates in a launch function;
+ *  - return value: 0 = ok, negative = error (mm_last_error() gives the text, thread-local);
+ *  - no torch types anywhere; plain pointers and sizes only.
+ *
+ * Device data layout ("count blocks"): cells are ordered by group and cut into blocks of <= 8192
+ * cells of ONE group.  Each block is stored gene-major as SELL-64 (sliced ELLPACK, 64 genes per slice,
+ * genes sorted by their nnz inside the block so a slice has no padding to speak of):
+ *      entry (uint32) = cell_local (13 bits) | count << 13 (19 bits, 0 = padding)
+ *      ent[blk_base[b] + slice_ptr[b][t] + j*64 + lane]   j < slice_w[b][t],  gene = perm[b][t*64+lane]
+ * so that lane-per-gene kernels read perfectly coalesced 256-B rows and need no cross-lane reduction.
+ */
+#ifndef MEMENTO_HIP_H
+#define MEMENTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_CELL_BITS 13
+#define MM_BLOCK_CELLS (1 << MM_CELL_BITS) /* max cells per count block */
+#define MM_MAX_COUNT ((1u << (32 - MM_CELL_BITS)) - 1u)
+
+const char *mm_last_error(void);
+int mm_version(void);
+int mm_device_count(void);
+int mm_set_device(int dev);
+
+/* raw device-memory helpers so a ctypes-only caller needs nothing but this library */
+int mm_malloc(void **d_ptr, size_t bytes);
+int mm_free(void *d_ptr);
+int mm_memset(void *d_ptr, int value, size_t bytes, void *stream);
+int mm_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int mm_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int mm_sync(void *stream);
+/* HIP-event timing of whatever is enqueued between begin and end on `stream` (bench.py roofline) */
+int mm_timer_create(void **timer);
+int mm_timer_begin(void *timer, void *stream);
+int mm_timer_end(void *timer, void *stream);
+int mm_timer_elapsed_ms(void *timer, float *ms); /* synchronises on the end event */
+int mm_timer_destroy(void *timer);
+
+/* ---- K3: row sums of the CSR, optionally restricted to a gene mask ---------------------------
+ * replaces X.sum(axis=1) / X.multiply(mask).sum(axis=1)   memento/estimator.py:65, :73 */
+int mm_csr_rowsum(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows,
+                  const uint8_t *d_gene_mask /* NULL = all genes */, double *d_out, void *stream);
+
+/* ---- K0: ingest = CSR -> group-ordered SELL count blocks --------------------------------------
+ * replaces util._select_cells(adata, group) = adata.X[mask].tocsc() per group
+ *   memento/util.py:8-13, memento/main.py:128
+ * d_cell_order[n_sel]: original cell index of every selected cell, sorted by group;
+ * d_blk_cell0[n_blocks+1]: block b covers cell_order[blk_cell0[b] .. blk_cell0[b+1]) (one group each).
+ * Step 1 counts nnz per (block, gene) and validates the data (integer valued, 0 < x <= MM_MAX_COUNT;
+ * d_status[0] != 0 afterwards means invalid data).  */
+int mm_sell_count(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
+                  const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, uint16_t *d_blk_cnt /* [nb][G] */,
+                  int32_t *d_status, void *stream);
+/* Step 2: per block sort genes by descending count -> rank/perm, slice widths/pointers and work items.
+ * n_slices = ceil(G/64).  A slice is stored as slice_w[t] rows of 64 lanes x 4 entries (one dwordx4 per
+ * lane per row; lane = gene slot, 4 consecutive entries of that gene).  slice_ptr is in rows, relative to
+ * the block; d_blk_rows[b] = rows of block b (host scans it into blk_base, in rows).  A work item is
+ * <= 64 rows of one slice; item_ptr[b][t] numbers them slice-major, d_blk_items[b] = items of block b. */
+int mm_sell_layout(const uint16_t *d_blk_cnt, int32_t n_blocks, int32_t n_genes, int32_t *d_rank /* [nb][G] */,
+                   int32_t *d_perm /* [nb][n_slices*64], -1 = no gene */, int32_t *d_slice_w /* [nb][n_slices] */,
+                   int32_t *d_slice_ptr /* [nb][n_slices+1] */, int32_t *d_item_ptr /* [nb][n_slices+1] */,
+                   int64_t *d_blk_rows /* [nb] */, int32_t *d_blk_items /* [nb] */, void *stream);
+/* Step 3: scatter entries (d_ent must be zero-filled, 256 uint32 per row, sum(blk_rows) rows). */
+int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
+                    const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, const int32_t *d_rank,
+                    const int32_t *d_slice_ptr, const int64_t *d_blk_base, uint32_t *d_ent, void *stream);
+
+/* ---- K1+K2: per-(item, gene slot) moment sums from the count blocks  (the HBM-roofline kernel) ---
+ * replaces estimator._hyper_1d_relative sparse branch  memento/estimator.py:177-180
+ *          and group_cells.mean(axis=0) / .max(axis=0)   memento/main.py:201, :206
+ * d_inv_sf[n_sel]: 1/size_factor per selected cell in block order.
+ * slab (each [sum(blk_items)][64]): S1 = sum x/sf, S2 = sum x^2/sf^2, S3 = sum x/sf^2 (fp64),
+ * SX = sum x (uint32, exact), MX = max x (uint32).  d_blk_item_base = exclusive scan of blk_items. */
+int mm_moments1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const int32_t *d_slice_w, const int32_t *d_slice_ptr,
+                      const int32_t *d_item_ptr, const int64_t *d_blk_item_base, const int32_t *d_blk_cell0,
+                      const double *d_inv_sf, int32_t n_blocks, int32_t n_genes, double *d_S1, double *d_S2, double *d_S3,
+                      uint32_t *d_SX, uint32_t *d_MX, void *stream);
+/* deterministic reduction of the slab over items and over the blocks of each group -> [n_groups][G] */
+int mm_moments1d_reduce(const double *d_S1, const double *d_S2, const double *d_S3, const uint32_t *d_SX, const uint32_t *d_MX,
+                        const int32_t *d_rank, const int32_t *d_item_ptr, const int64_t *d_blk_item_base,
+                        const int32_t *d_grp_blk0 /* [n_groups+1] first block of each group */, int32_t n_groups,
+                        int32_t n_genes, double *d_out_S /* [3][n_groups][G] */, uint64_t *d_out_sumx /* [n_groups][G] */,
+                        uint32_t *d_out_maxx /* [n_groups][G] */, void *stream);
+
+/* ---- K5: integer histograms keyed (group, gene, sf_bin, count) --------------------------------
+ * replaces bootstrap._unique_expr's np.unique over cells  memento/bootstrap.py:62-71 (the bins as a SET;
+ * their replay ORDER is applied by mm_bins_order).  Pair p = gene_slot*n_groups + group for the tested
+ * genes; d_gene_pairbase[G] = gene_slot*n_groups or -1 if the gene is not tested.  Table of pair p starts
+ * at d_tab_ptr[p], is [n_sf_bins][xcap[p]] uint32 with xcap[p] = max count of the pair + 1
+ * (column 0 is filled with the zero-count cells by mm_bins_count). Tables must be zeroed by the caller. */
+int mm_hist1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const int32_t *d_slice_w, const int32_t *d_slice_ptr,
+                   const int32_t *d_item_ptr, const int32_t *d_perm, const int32_t *d_blk_cell0, const int32_t *d_blk_group,
+                   const uint8_t *d_sf_bin /* [n_sel] block order */, int32_t n_blocks, int32_t n_genes,
+                   const int32_t *d_gene_pairbase, const int64_t *d_tab_ptr, const int32_t *d_xcap, uint32_t *d_tab, void *stream);
+/* zero-count column + number of non-empty bins per pair.  d_grp_bin_cells[n_groups][n_sf_bins] = cells per (group, sf bin) */
+int mm_bins_count(uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap, int64_t n_pairs, int32_t n_groups,
+                  int32_t n_sf_bins, const uint32_t *d_grp_bin_cells, int32_t *d_K /* [n_pairs] */, void *stream);
+
+/* ---- K5b+K6 prep: order the bins like np.unique(code) and lay them out for the bootstrap ---------
+ * code = count*r1 + r0*approx_sf[sf_bin] in IEEE fp64 (memento/bootstrap.py:62-67); ascending.
+ * Pairs are assigned to lanes of 64-wide tiles (d_pair_slot[p] = tile*64+lane or -1 to skip);
+ * tile t owns bin rows [tile_ptr[t], tile_ptr[t+1]) of 64 lanes each.  Per bin the kernel writes
+ *   pix = mult/N_g, v = count, a = 1/sf, b = 1/sf^2, c1 = (1-q)*count, v2 = count^2   (fp64 each)
+ * at [ (tile_ptr[t]+k)*64 + lane ].  d_status[0] is set if two bins of a pair collide in code. */
+int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap, const int32_t *d_K,
+                  const int64_t *d_pair_list, int64_t n_list /* pairs handled by this launch */,
+                  int32_t big /* 0: K <= 1024 (one wave per pair); 1: K <= 8192 (512 threads per pair) */, int32_t n_groups,
+                  int32_t n_sf_bins, const double *d_sf_table /* [n_sf_bins] approx size factor of each bin */,
+                  const double *d_r1, const double *d_r0 /* per pair */, const int64_t *d_pair_slot, const int64_t *d_tile_ptr,
+                  const double *d_grp_ncells /* [n_groups] */, const double *d_grp_q /* [n_groups] */, double *d_pix, double *d_v,
+                  double *d_a, double *d_b, double *d_c1, double *d_v2, int32_t *d_status, void *stream);
+
+/* ---- K6+K7: replay bootstrap -- numpy Generator(PCG64).multinomial draw-for-draw + replicate moments
+ * replaces bootstrap._bootstrap_1d  memento/bootstrap.py:97-110 and the tuple branch of
+ * estimator._hyper_1d_relative  memento/estimator.py:171-174, :182-183.
+ * One lane per (gene, group) pair, one sequential PCG64 stream per lane (the reference re-seeds PCG64(5)
+ * for every pair, bootstrap.py:102).  pcg_state = {state_hi, state_lo, inc_hi, inc_lo}.
+ * Writes mean_b / var_b to d_out_mean[row*ld + 1 + b], row = d_slot_row[slot]; K<=1 pairs get NaN rows.
+ * d_w_dump (optional, NULL in production) receives the int32 weights [slot][k][b] with stride kmax_dump. */
+int mm_boot1d_replay(const double *d_pix, const double *d_v, const double *d_a, const double *d_b, const double *d_c1,
+                     const double *d_v2, const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K,
+                     const double *d_slot_nobs, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
+                     int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream);
+
+/* ---- K8: residual variance, invalid-replicate fill, log  ---------------------------------------
+ * replaces estimator._residual_variance + hypothesis_test._fill + np.log
+ *   memento/estimator.py:103-111, memento/hypothesis_test.py:186-197.
+ * In place on rows [n_rows][ld]; column 0 (true values, already logged by the host) is left alone.
+ * fill_mode 0: replace invalid entries by a uniformly chosen valid replicate using a counter-based
+ *   RNG (own stream: statistically equivalent to np.random.choice, not the same draws);
+ * fill_mode 1: leave invalid entries as NaN (the strict host driver patches them with np.random).
+ * d_n_invalid[row][2] = number of invalid (mean, res_var) replicates; a row with no valid entry is
+ * reported as -1. */
+int mm_boot_fill_log(double *d_mean, double *d_var, int64_t n_rows, int64_t ld, int32_t num_boot, const double mv_fit[3],
+                     int32_t fill_mode, uint64_t fill_seed, int32_t *d_n_invalid, void *stream);
+
+/* ---- K9+K10: per-test linear contraction over groups and null statistics ------------------------
+ * replaces hypothesis_test._regress_1d (linear part) and the counting part of _compute_asl
+ *   memento/hypothesis_test.py:249-251, :262-271, :290-298, :62-92.
+ * test t: rows of gene test_gene[t] are [gene*n_groups + j]; coef_b = sum_j W[t][j] * y[row_j][b] over
+ * good groups (d_good[gene][j] != 0); replicate b is dropped if any good row is non-finite in either
+ * d_ym or d_yv (valid_boostrap_iters).  which = 0 uses d_ym, 1 uses d_yv as the response.
+ * d_coef[t][ld] receives the coefficient row (NaN where dropped); d_stats[t][8] =
+ *   {coef0, se (nanstd, ddof 0), n_valid_null, extreme_count, null_mean, all_equal, min, max}. */
+int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups,
+                      const int32_t *d_test_gene, const double *d_W /* [n_tests][n_groups] */, const uint8_t *d_good /* [n_genes][n_groups] */,
+                      int64_t n_tests, int32_t which, double *d_coef, double *d_stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMENTO_HIP_H */

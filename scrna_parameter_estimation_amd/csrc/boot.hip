@@ -1,0 +1,194 @@
+// boot.hip -- K6+K7+K8: the unique-value bootstrap, replayed draw-for-draw against numpy.
+//
+// Reference behaviour replaced:
+//   bootstrap._bootstrap_1d            memento/bootstrap.py:97-110
+//     gen = Generator(PCG64(5)); w = gen.multinomial(N_g, counts/counts.sum(), size=B).T
+//   estimator._hyper_1d_relative tuple branch   memento/estimator.py:171-174, :182-183
+//   estimator._residual_variance + hypothesis_test._fill + np.log
+//                                      memento/estimator.py:103-111, hypothesis_test.py:23-33, :186-197
+//
+// One lane = one (gene, group) pair = one sequential PCG64 stream (the reference re-seeds PCG64(5) per
+// pair).  The 64 pairs of a tile walk their bins in lock step so every operand load is a coalesced
+// 512-B row; the multinomial weights never leave registers (the K x B matrix is never materialised).
+// fp64, contraction OFF (-ffp-contract=off): replicate means/variances are bit-identical to numpy's.
+#include "mm_common.h"
+#include "npy_rng.h"
+
+__global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict__ pix, const double *__restrict__ v,
+                                                       const double *__restrict__ a, const double *__restrict__ b,
+                                                       const double *__restrict__ c1, const double *__restrict__ v2,
+                                                       const int64_t *__restrict__ tile_ptr, int64_t n_tiles,
+                                                       const int32_t *__restrict__ slot_K, const double *__restrict__ slot_nobs,
+                                                       const int64_t *__restrict__ slot_row, uint64_t st0, uint64_t st1,
+                                                       uint64_t st2, uint64_t st3, int32_t num_boot, int64_t ld,
+                                                       double *__restrict__ out_mean, double *__restrict__ out_var,
+                                                       int32_t *__restrict__ w_dump, int32_t kmax_dump) {
+  int lane = mm_lane();
+  int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (tile >= n_tiles) return;
+  int64_t slot = tile * 64 + lane;
+  int K = slot_K[slot];
+  int64_t row = slot_row[slot];
+  if (K <= 0 || row < 0) K = 0;  // unused lane
+  int64_t row0 = tile_ptr[tile];
+  int kmax = (int)(tile_ptr[tile + 1] - row0);
+  double nobs = slot_nobs[slot];
+  int64_t n = (int64_t)nobs;
+  double *om = out_mean + row * ld + 1;
+  double *ov = out_var + row * ld + 1;
+  if (K == 1) {  // bootstrap.py:97-98: a single bin -> all-NaN replicates
+    for (int r = 0; r < num_boot; r++) {
+      om[r] = NAN;
+      ov[r] = NAN;
+    }
+  }
+  npyrng::Pcg64 g{st0, st1, st2, st3};
+  const bool run = K >= 2;
+  for (int r = 0; r < num_boot; r++) {
+    double M1 = 0.0, M2 = 0.0, rem = 1.0;
+    int64_t dn = n;
+    bool live = true;
+    for (int k = 0; k < kmax; k++) {
+      if (run && k < K) {
+        int64_t o = (row0 + k) * 64 + lane;
+        int64_t w;
+        if (k < K - 1) {
+          w = 0;
+          if (live) {
+            double pk = pix[o];
+            w = npyrng::binomial(g, pk / rem, dn);
+            dn -= w;
+            if (dn <= 0) live = false;
+            else rem -= pk;
+          }
+        } else {
+          w = dn > 0 ? dn : 0;
+        }
+        if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = (int32_t)w;
+        if (w != 0) {
+          double wd = (double)w;
+          double bb = b[o];
+          M1 += (v[o] * wd) * a[o];
+          M2 += (v2[o] * wd) * bb - (c1[o] * wd) * bb;
+        }
+      }
+    }
+    if (run) {
+      double mean = M1 / nobs;
+      double var = M2 / nobs - mean * mean;
+      om[r] = mean;
+      ov[r] = var;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser (counter-based fill RNG)
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// One wave per row.  Pass 1: res_var, validity, counts.  Pass 2 (fill_mode 0): each invalid entry takes
+// a uniformly chosen VALID replicate (stored negated so later readers still see it as "not original").
+// Pass 3: log.
+__global__ __launch_bounds__(256) void k_boot_fill_log(double *__restrict__ mean, double *__restrict__ var, int64_t n_rows,
+                                                       int64_t ld, int32_t num_boot, double f0, double f1, double f2,
+                                                       int32_t fill_mode, uint64_t seed, int32_t *__restrict__ n_invalid) {
+  int lane = mm_lane();
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= n_rows) return;
+  double *m = mean + row * ld + 1;
+  double *s = var + row * ld + 1;
+  int bad_m = 0, bad_v = 0;
+  for (int r = lane; r < num_boot; r += 64) {
+    double mm = m[r], vv = s[r];
+    double rv = NAN;
+    if (mm > 0.0 && vv > 0.0) {
+      double lm = log(mm);
+      double pred = ((0.0 * lm + f0) * lm + f1) * lm + f2;  // np.poly1d Horner order
+      rv = exp(log(vv) - pred);
+    }
+    if (!(mm > 0.0)) {
+      m[r] = NAN;
+      bad_m++;
+    }
+    if (!(rv > 0.0)) {
+      rv = NAN;
+      bad_v++;
+    }
+    s[r] = rv;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    bad_m += __shfl_xor(bad_m, off, 64);
+    bad_v += __shfl_xor(bad_v, off, 64);
+  }
+  bool none_m = bad_m == num_boot, none_v = bad_v == num_boot;
+  if (lane == 0) {
+    n_invalid[row * 2] = none_m ? -1 : bad_m;
+    n_invalid[row * 2 + 1] = none_v ? -1 : bad_v;
+  }
+  __threadfence_block();
+  if (fill_mode == 0) {
+    for (int which = 0; which < 2; which++) {
+      double *x = which ? s : m;
+      int nb = which ? bad_v : bad_m;
+      if (nb == 0 || nb == num_boot) continue;
+      for (int r = lane; r < num_boot; r += 64) {
+        double cur = x[r];
+        if (!(cur > 0.0) && !(cur < 0.0)) {  // NaN => invalid and not yet filled
+          uint64_t ctr = mix64(seed ^ mix64((uint64_t)row * 2 + which) ^ ((uint64_t)r << 20));
+          double pick = NAN;
+          for (int attempt = 0; attempt < 4096; attempt++) {
+            ctr = mix64(ctr + attempt);
+            int idx = (int)(ctr % (uint64_t)num_boot);
+            double c = x[idx];
+            if (c > 0.0) {
+              pick = c;
+              break;
+            }
+          }
+          x[r] = -pick;
+        }
+      }
+      __threadfence_block();
+    }
+  }
+  for (int r = lane; r < num_boot; r += 64) {
+    double mm = m[r], vv = s[r];
+    m[r] = log(fabs(mm));  // NaN stays NaN; filled entries were stored negated
+    s[r] = log(fabs(vv));
+  }
+}
+
+extern "C" {
+
+int mm_boot1d_replay(const double *d_pix, const double *d_v, const double *d_a, const double *d_b, const double *d_c1,
+                     const double *d_v2, const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K,
+                     const double *d_slot_nobs, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
+                     int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream) {
+  MM_ARG(d_pix && d_v && d_a && d_b && d_c1 && d_v2 && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_row && pcg_state);
+  MM_ARG(d_out_mean && d_out_var && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_tiles == 0) return MM_OK;
+  int64_t blocks = (n_tiles + 3) / 4;
+  hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pix, d_v, d_a, d_b, d_c1, d_v2,
+                     d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2], pcg_state[3],
+                     num_boot, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_boot_fill_log(double *d_mean, double *d_var, int64_t n_rows, int64_t ld, int32_t num_boot, const double mv_fit[3],
+                     int32_t fill_mode, uint64_t fill_seed, int32_t *d_n_invalid, void *stream) {
+  MM_ARG(d_mean && d_var && mv_fit && d_n_invalid && n_rows >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  MM_ARG(fill_mode == 0 || fill_mode == 1);
+  if (n_rows == 0) return MM_OK;
+  int64_t blocks = (n_rows + 3) / 4;
+  hipLaunchKernelGGL(k_boot_fill_log, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_mean, d_var, n_rows, ld, num_boot,
+                     mv_fit[0], mv_fit[1], mv_fit[2], fill_mode, fill_seed, d_n_invalid);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

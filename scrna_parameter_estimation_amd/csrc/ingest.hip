@@ -1,0 +1,255 @@
+// ingest.hip -- K0: CSR -> group-ordered SELL-64x4 "count blocks", and K3 row sums.
+//
+// Reference behaviour replaced: util._select_cells -> adata.X[mask].tocsc() per group
+// (memento/util.py:8-13, main.py:128) and X.sum(axis=1) / X.multiply(mask).sum(axis=1)
+// (memento/estimator.py:65, :73).  Everything here is integer/index work: bit-exact by construction.
+#include "mm_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K3: one wave per CSR row, coalesced index/data reads, __shfl_xor reduction (HBM-bound).
+__global__ __launch_bounds__(256) void k_csr_rowsum(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                    const float *__restrict__ data, int64_t n_rows,
+                                                    const uint8_t *__restrict__ mask, double *__restrict__ out) {
+  int lane = mm_lane();
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n_rows; r += nwaves) {
+    int64_t s = indptr[r], e = indptr[r + 1];
+    double acc = 0.0;
+    for (int64_t i = s + lane; i < e; i += 64) {
+      float x = data[i];
+      if (mask == nullptr || mask[indices[i]]) acc += (double)x;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[r] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0 step 1: nnz per (block, gene) with LDS counters; validates the counts.
+#define CNT_TILE 32768
+__global__ __launch_bounds__(1024) void k_sell_count(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                     const float *__restrict__ data, const int32_t *__restrict__ cell_order,
+                                                     const int32_t *__restrict__ blk_cell0, int32_t n_genes,
+                                                     uint16_t *__restrict__ blk_cnt, int32_t *__restrict__ status) {
+  __shared__ uint32_t cnt[CNT_TILE];
+  int b = blockIdx.x;
+  int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
+  int lane = mm_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int bad = 0;
+  for (int g0 = 0; g0 < n_genes; g0 += CNT_TILE) {
+    int gt = min(CNT_TILE, n_genes - g0);
+    for (int i = threadIdx.x; i < gt; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    for (int r = c0 + wave; r < c1; r += nw) {
+      int cell = cell_order[r];
+      int64_t s = indptr[cell], e = indptr[cell + 1];
+      for (int64_t i = s + lane; i < e; i += 64) {
+        int g = indices[i];
+        float x = data[i];
+        if (g0 == 0) {
+          // counts must be positive integers that fit the 19-bit field
+          if (!(x >= 1.0f && x <= (float)MM_MAX_COUNT && x == floorf(x)) || g < 0 || g >= n_genes) bad = 1;
+        }
+        unsigned gl = (unsigned)(g - g0);
+        if (gl < (unsigned)gt) atomicAdd(&cnt[gl], 1u);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < gt; i += blockDim.x) blk_cnt[(int64_t)b * n_genes + g0 + i] = (uint16_t)cnt[i];
+    __syncthreads();
+  }
+  if (bad) atomicOr(status, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0 step 2: per block, rank genes by descending nnz (counting sort on the length), derive the slice
+// widths (in dwordx4 rows), slice pointers (rows) and work-item pointers.
+#define LAYOUT_MAXLEN (MM_BLOCK_CELLS + 1)
+__global__ __launch_bounds__(1024) void k_sell_layout(const uint16_t *__restrict__ blk_cnt, int32_t n_genes, int32_t n_slices,
+                                                      int32_t *__restrict__ rank, int32_t *__restrict__ perm,
+                                                      int32_t *__restrict__ slice_w, int32_t *__restrict__ slice_ptr,
+                                                      int32_t *__restrict__ item_ptr, int64_t *__restrict__ blk_rows,
+                                                      int32_t *__restrict__ blk_items) {
+  extern __shared__ uint32_t smem[];
+  uint32_t *start = smem;                                  // [LAYOUT_MAXLEN] (+ pad)
+  uint32_t *scan_tmp = smem + LAYOUT_MAXLEN + 3;           // [1024]
+  uint16_t *len_by_rank = (uint16_t *)(scan_tmp + 1024);   // [n_slices*64]
+  int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const uint16_t *cnt = blk_cnt + (int64_t)b * n_genes;
+  for (int i = tid; i < LAYOUT_MAXLEN; i += nt) start[i] = 0;
+  for (int i = tid; i < n_slices * 64; i += nt) len_by_rank[i] = 0;
+  __syncthreads();
+  for (int g = tid; g < n_genes; g += nt) atomicAdd(&start[cnt[g]], 1u);
+  __syncthreads();
+  // start[L] <- number of genes with length > L  (descending exclusive scan over L)
+  {
+    const int per = (LAYOUT_MAXLEN + 1023) / 1024;  // 9
+    int hi = LAYOUT_MAXLEN - 1 - tid * per;         // this thread owns L = hi, hi-1, ..., hi-per+1
+    uint32_t local = 0;
+    for (int k = 0; k < per; k++) {
+      int L = hi - k;
+      if (L >= 0) local += start[L];
+    }
+    scan_tmp[tid] = local;
+    __syncthreads();
+    // inclusive scan of scan_tmp (Hillis-Steele, 1024 threads)
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t v = tid >= off ? scan_tmp[tid - off] : 0;
+      __syncthreads();
+      scan_tmp[tid] += v;
+      __syncthreads();
+    }
+    uint32_t run = scan_tmp[tid] - local;  // exclusive prefix = genes with L greater than this thread's range
+    for (int k = 0; k < per; k++) {
+      int L = hi - k;
+      if (L >= 0) {
+        uint32_t h = start[L];
+        start[L] = run;
+        run += h;
+      }
+    }
+  }
+  __syncthreads();
+  for (int g = tid; g < n_genes; g += nt) {
+    uint32_t L = cnt[g];
+    uint32_t s = atomicAdd(&start[L], 1u);  // ties broken by arrival; slot order is irrelevant downstream
+    rank[(int64_t)b * n_genes + g] = (int32_t)s;
+    perm[(int64_t)b * n_slices * 64 + s] = g;
+    len_by_rank[s] = (uint16_t)L;
+  }
+  for (int s = n_genes + tid; s < n_slices * 64; s += nt) perm[(int64_t)b * n_slices * 64 + s] = -1;
+  __syncthreads();
+  // slice widths in dwordx4 rows, pointers by exclusive scan (n_slices <= 1024 * k handled by a serial carry)
+  uint32_t carry_rows = 0, carry_items = 0;
+  for (int t0 = 0; t0 < n_slices; t0 += 1024) {
+    int t = t0 + tid;
+    uint32_t w4 = 0, items = 0;
+    if (t < n_slices) {
+      w4 = ((uint32_t)len_by_rank[t * 64] + MM_JVEC - 1) / MM_JVEC;
+      items = (w4 + MM_ITEM_ROWS - 1) / MM_ITEM_ROWS;
+      slice_w[(int64_t)b * n_slices + t] = (int32_t)w4;
+    }
+    // two scans sharing scan_tmp: rows then items
+    for (int pass = 0; pass < 2; pass++) {
+      uint32_t mine = pass == 0 ? w4 : items;
+      __syncthreads();
+      scan_tmp[tid] = mine;
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = tid >= off ? scan_tmp[tid - off] : 0;
+        __syncthreads();
+        scan_tmp[tid] += v;
+        __syncthreads();
+      }
+      uint32_t excl = scan_tmp[tid] - mine + (pass == 0 ? carry_rows : carry_items);
+      uint32_t total = scan_tmp[1023];
+      if (t < n_slices) {
+        if (pass == 0) slice_ptr[(int64_t)b * (n_slices + 1) + t] = (int32_t)excl;
+        else item_ptr[(int64_t)b * (n_slices + 1) + t] = (int32_t)excl;
+      }
+      if (pass == 0) carry_rows += total; else carry_items += total;
+    }
+  }
+  if (tid == 0) {
+    slice_ptr[(int64_t)b * (n_slices + 1) + n_slices] = (int32_t)carry_rows;
+    item_ptr[(int64_t)b * (n_slices + 1) + n_slices] = (int32_t)carry_items;
+    blk_rows[b] = carry_rows;
+    blk_items[b] = (int32_t)carry_items;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0 step 3: scatter.  One wave per cell row (coalesced CSR reads); per-gene cursors live in LDS as
+// packed 16-bit halves; each entry lands at  (blk_base + slice_ptr[t] + j/4)*256 + lane*4 + j%4.
+__global__ __launch_bounds__(1024) void k_sell_scatter(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                       const float *__restrict__ data, const int32_t *__restrict__ cell_order,
+                                                       const int32_t *__restrict__ blk_cell0, int32_t n_genes, int32_t n_slices,
+                                                       const int32_t *__restrict__ rank, const int32_t *__restrict__ slice_ptr,
+                                                       const int64_t *__restrict__ blk_base, uint32_t *__restrict__ ent) {
+  extern __shared__ uint32_t smem[];
+  uint32_t *cur = smem;                         // [(n_genes+1)/2] packed u16 cursors
+  int32_t *sptr = (int32_t *)(smem + (n_genes + 1) / 2);  // [n_slices]
+  int b = blockIdx.x;
+  int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
+  int lane = mm_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < (n_genes + 1) / 2; i += blockDim.x) cur[i] = 0;
+  for (int i = threadIdx.x; i < n_slices; i += blockDim.x) sptr[i] = slice_ptr[(int64_t)b * (n_slices + 1) + i];
+  __syncthreads();
+  const int32_t *rk = rank + (int64_t)b * n_genes;
+  int64_t base = blk_base[b];
+  for (int r = c0 + wave; r < c1; r += nw) {
+    int cell = cell_order[r];
+    uint32_t cell_local = (uint32_t)(r - c0);
+    int64_t s = indptr[cell], e = indptr[cell + 1];
+    for (int64_t i = s + lane; i < e; i += 64) {
+      int g = indices[i];
+      uint32_t x = (uint32_t)data[i];
+      int sl = rk[g];
+      unsigned sh = (g & 1) * 16;
+      uint32_t old = atomicAdd(&cur[g >> 1], 1u << sh);
+      uint32_t j = (old >> sh) & 0xFFFFu;
+      int64_t row = base + sptr[sl >> 6] + (j >> 2);
+      ent[row * 256 + (sl & 63) * 4 + (j & 3)] = cell_local | (x << MM_CELL_BITS);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int mm_csr_rowsum(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows,
+                  const uint8_t *d_gene_mask, double *d_out, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_data && d_out && n_rows >= 0);
+  if (n_rows == 0) return MM_OK;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_csr_rowsum, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_data, n_rows,
+                     d_gene_mask, d_out);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_sell_count(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
+                  const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, uint16_t *d_blk_cnt, int32_t *d_status,
+                  void *stream) {
+  MM_ARG(d_indptr && d_indices && d_data && d_cell_order && d_blk_cell0 && d_blk_cnt && d_status);
+  MM_ARG(n_blocks >= 0 && n_genes > 0);
+  if (n_blocks == 0) return MM_OK;
+  hipLaunchKernelGGL(k_sell_count, dim3(n_blocks), dim3(1024), 0, (hipStream_t)stream, d_indptr, d_indices, d_data, d_cell_order,
+                     d_blk_cell0, n_genes, d_blk_cnt, d_status);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_sell_layout(const uint16_t *d_blk_cnt, int32_t n_blocks, int32_t n_genes, int32_t *d_rank, int32_t *d_perm,
+                   int32_t *d_slice_w, int32_t *d_slice_ptr, int32_t *d_item_ptr, int64_t *d_blk_rows, int32_t *d_blk_items,
+                   void *stream) {
+  MM_ARG(d_blk_cnt && d_rank && d_perm && d_slice_w && d_slice_ptr && d_item_ptr && d_blk_rows && d_blk_items);
+  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_genes <= 60000);
+  if (n_blocks == 0) return MM_OK;
+  int32_t n_slices = (n_genes + 63) / 64;
+  size_t shm = (size_t)(LAYOUT_MAXLEN + 3 + 1024) * 4 + (size_t)n_slices * 64 * 2;
+  MM_HIP(hipFuncSetAttribute((const void *)k_sell_layout, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_sell_layout, dim3(n_blocks), dim3(1024), shm, (hipStream_t)stream, d_blk_cnt, n_genes, n_slices, d_rank,
+                     d_perm, d_slice_w, d_slice_ptr, d_item_ptr, d_blk_rows, d_blk_items);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
+                    const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, const int32_t *d_rank,
+                    const int32_t *d_slice_ptr, const int64_t *d_blk_base, uint32_t *d_ent, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_data && d_cell_order && d_blk_cell0 && d_rank && d_slice_ptr && d_blk_base && d_ent);
+  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_genes <= 60000);
+  if (n_blocks == 0) return MM_OK;
+  int32_t n_slices = (n_genes + 63) / 64;
+  size_t shm = (size_t)((n_genes + 1) / 2 + n_slices) * 4;
+  MM_HIP(hipFuncSetAttribute((const void *)k_sell_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_sell_scatter, dim3(n_blocks), dim3(1024), shm, (hipStream_t)stream, d_indptr, d_indices, d_data, d_cell_order,
+                     d_blk_cell0, n_genes, n_slices, d_rank, d_slice_ptr, d_blk_base, d_ent);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

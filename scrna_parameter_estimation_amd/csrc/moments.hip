@@ -1,0 +1,162 @@
+// moments.hip -- K1+K2: per-gene 1D moment sums from the SELL count blocks.  THE HBM-roofline kernel.
+//
+// Reference behaviour replaced (memento/estimator.py:177-180, sparse branch of _hyper_1d_relative):
+//     S1 = sum_c x/sf_c,  S2 = sum_c x^2/sf_c^2,  S3 = sum_c x/sf_c^2    (three CSC.vector products)
+// and memento/main.py:201, :206 (plain per-group mean and max of the counts, for the gene filters).
+//
+// Mapping: one lane per gene of a 64-gene slice, so the 5 accumulators live in registers and there is NO
+// cross-lane reduction; a wave streams its work item (<= 64 rows of 1 KiB, one dwordx4 per lane per row,
+// perfectly coalesced); the block's per-cell 1/sf (fp64) is staged once in LDS and gathered per entry.
+// Algorithmic bytes per entry: 4 (the packed entry); fp64 accumulation.
+#include "mm_common.h"
+
+#define K1_THREADS 512
+#define K1_UNROLL 4
+
+__device__ __forceinline__ void k1_acc(uint32_t e, const double *__restrict__ w_lds, double &a1, double &a2, double &a3,
+                                       uint32_t &sx, uint32_t &mx) {
+  uint32_t x = e >> MM_CELL_BITS;
+  double w = w_lds[e & (MM_BLOCK_CELLS - 1)];
+  double xd = (double)x;
+  double xw = xd * w;
+  double xw2 = xw * w;
+  a1 += xw;
+  a3 += xw2;
+  a2 += xd * xw2;
+  sx += x;
+  mx = max(mx, x);
+}
+
+__global__ __launch_bounds__(K1_THREADS) void k_moments1d_sell(const u32x4 *__restrict__ ent, const int64_t *__restrict__ blk_base,
+                                                               const int32_t *__restrict__ slice_w, const int32_t *__restrict__ slice_ptr,
+                                                               const int32_t *__restrict__ item_ptr, const int64_t *__restrict__ blk_item_base,
+                                                               const int32_t *__restrict__ blk_cell0, const double *__restrict__ inv_sf,
+                                                               int32_t n_slices, int32_t split, double *__restrict__ S1,
+                                                               double *__restrict__ S2, double *__restrict__ S3,
+                                                               uint32_t *__restrict__ SX, uint32_t *__restrict__ MX) {
+  __shared__ double w_lds[MM_BLOCK_CELLS];
+  int b = blockIdx.x / split, part = blockIdx.x % split;
+  int c0 = blk_cell0[b], nc = blk_cell0[b + 1] - c0;
+  for (int i = threadIdx.x; i < MM_BLOCK_CELLS; i += K1_THREADS) w_lds[i] = i < nc ? inv_sf[c0 + i] : 0.0;
+  __syncthreads();
+  int lane = mm_lane();
+  int wave = part * (K1_THREADS / 64) + (threadIdx.x >> 6);
+  int nwaves = split * (K1_THREADS / 64);
+  const int32_t *sw = slice_w + (int64_t)b * n_slices;
+  const int32_t *sp = slice_ptr + (int64_t)b * (n_slices + 1);
+  const int32_t *ip = item_ptr + (int64_t)b * (n_slices + 1);
+  int n_items = ip[n_slices];
+  int64_t base = blk_base[b];
+  int64_t ibase = blk_item_base[b];
+  // items are numbered slice-major; walk slices, taking this wave's share of the item ids
+  int t = 0;
+  for (int item = wave; item < n_items; item += nwaves) {
+    while (ip[t + 1] <= item) t++;  // wave-uniform; slices are visited in increasing order
+    int k = item - ip[t];
+    int r0 = k * MM_ITEM_ROWS;
+    int r1 = min(sw[t], r0 + MM_ITEM_ROWS);
+    const u32x4 *p = ent + (base + sp[t] + r0) * 64 + lane;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    uint32_t sx = 0, mx = 0;
+    int nr = r1 - r0, r = 0;
+    for (; r + K1_UNROLL <= nr; r += K1_UNROLL) {
+      u32x4 e[K1_UNROLL];
+#pragma unroll
+      for (int u = 0; u < K1_UNROLL; u++) e[u] = __builtin_nontemporal_load(p + (int64_t)(r + u) * 64);
+#pragma unroll
+      for (int u = 0; u < K1_UNROLL; u++) {
+        k1_acc(e[u].x, w_lds, a1, a2, a3, sx, mx);
+        k1_acc(e[u].y, w_lds, a1, a2, a3, sx, mx);
+        k1_acc(e[u].z, w_lds, a1, a2, a3, sx, mx);
+        k1_acc(e[u].w, w_lds, a1, a2, a3, sx, mx);
+      }
+    }
+    for (; r < nr; r++) {
+      u32x4 e = __builtin_nontemporal_load(p + (int64_t)r * 64);
+      k1_acc(e.x, w_lds, a1, a2, a3, sx, mx);
+      k1_acc(e.y, w_lds, a1, a2, a3, sx, mx);
+      k1_acc(e.z, w_lds, a1, a2, a3, sx, mx);
+      k1_acc(e.w, w_lds, a1, a2, a3, sx, mx);
+    }
+    int64_t o = (ibase + item) * 64 + lane;
+    S1[o] = a1;
+    S2[o] = a2;
+    S3[o] = a3;
+    SX[o] = sx;
+    MX[o] = mx;
+  }
+}
+
+// Deterministic reduction over the items of a gene's slice and over the blocks of a group.
+__global__ __launch_bounds__(256) void k_moments1d_reduce(const double *__restrict__ S1, const double *__restrict__ S2,
+                                                          const double *__restrict__ S3, const uint32_t *__restrict__ SX,
+                                                          const uint32_t *__restrict__ MX, const int32_t *__restrict__ rank,
+                                                          const int32_t *__restrict__ item_ptr, const int64_t *__restrict__ blk_item_base,
+                                                          const int32_t *__restrict__ grp_blk0, int32_t n_groups, int32_t n_genes,
+                                                          int32_t n_slices, double *__restrict__ out_S, uint64_t *__restrict__ out_sumx,
+                                                          uint32_t *__restrict__ out_maxx) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  int grp = blockIdx.y;
+  if (g >= n_genes) return;
+  double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  uint64_t sx = 0;
+  uint32_t mx = 0;
+  for (int b = grp_blk0[grp]; b < grp_blk0[grp + 1]; b++) {
+    int s = rank[(int64_t)b * n_genes + g];
+    int t = s >> 6, ln = s & 63;
+    const int32_t *ip = item_ptr + (int64_t)b * (n_slices + 1);
+    int64_t ib = blk_item_base[b];
+    for (int it = ip[t]; it < ip[t + 1]; it++) {
+      int64_t o = (ib + it) * 64 + ln;
+      a1 += S1[o];
+      a2 += S2[o];
+      a3 += S3[o];
+      sx += SX[o];
+      mx = max(mx, MX[o]);
+    }
+  }
+  int64_t o = (int64_t)grp * n_genes + g;
+  int64_t plane = (int64_t)n_groups * n_genes;
+  out_S[o] = a1;
+  out_S[plane + o] = a2;
+  out_S[2 * plane + o] = a3;
+  out_sumx[o] = sx;
+  out_maxx[o] = mx;
+}
+
+extern "C" {
+
+int mm_moments1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const int32_t *d_slice_w, const int32_t *d_slice_ptr,
+                      const int32_t *d_item_ptr, const int64_t *d_blk_item_base, const int32_t *d_blk_cell0,
+                      const double *d_inv_sf, int32_t n_blocks, int32_t n_genes, double *d_S1, double *d_S2, double *d_S3,
+                      uint32_t *d_SX, uint32_t *d_MX, void *stream) {
+  MM_ARG(d_ent && d_blk_base && d_slice_w && d_slice_ptr && d_item_ptr && d_blk_item_base && d_blk_cell0 && d_inv_sf);
+  MM_ARG(d_S1 && d_S2 && d_S3 && d_SX && d_MX && n_blocks >= 0 && n_genes > 0);
+  if (n_blocks == 0) return MM_OK;
+  int32_t n_slices = (n_genes + 63) / 64;
+  // enough workgroups to fill 256 CUs x 2 resident (64 KiB LDS each)
+  int split = (2048 + n_blocks - 1) / n_blocks;
+  if (split < 1) split = 1;
+  if (split > 64) split = 64;
+  hipLaunchKernelGGL(k_moments1d_sell, dim3((unsigned)(n_blocks * split)), dim3(K1_THREADS), 0, (hipStream_t)stream,
+                     (const u32x4 *)d_ent, d_blk_base, d_slice_w, d_slice_ptr, d_item_ptr, d_blk_item_base, d_blk_cell0, d_inv_sf,
+                     n_slices, split, d_S1, d_S2, d_S3, d_SX, d_MX);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_moments1d_reduce(const double *d_S1, const double *d_S2, const double *d_S3, const uint32_t *d_SX, const uint32_t *d_MX,
+                        const int32_t *d_rank, const int32_t *d_item_ptr, const int64_t *d_blk_item_base,
+                        const int32_t *d_grp_blk0, int32_t n_groups, int32_t n_genes, double *d_out_S, uint64_t *d_out_sumx,
+                        uint32_t *d_out_maxx, void *stream) {
+  MM_ARG(d_S1 && d_S2 && d_S3 && d_SX && d_MX && d_rank && d_item_ptr && d_blk_item_base && d_grp_blk0);
+  MM_ARG(d_out_S && d_out_sumx && d_out_maxx && n_groups > 0 && n_genes > 0);
+  int32_t n_slices = (n_genes + 63) / 64;
+  hipLaunchKernelGGL(k_moments1d_reduce, dim3((n_genes + 255) / 256, n_groups), dim3(256), 0, (hipStream_t)stream, d_S1, d_S2, d_S3,
+                     d_SX, d_MX, d_rank, d_item_ptr, d_blk_item_base, d_grp_blk0, n_groups, n_genes, n_slices, d_out_S,
+                     d_out_sumx, d_out_maxx);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+"""Host-side driver of the HIP kernels: device CSR, SELL count blocks, moments, histograms, bootstrap.
+
+torch is used only as plumbing here (device allocations, H2D/D2H copies, the current HIP stream); all
+arithmetic on the hot path happens in libmemento_hip.so (csrc/*.hip) through the C-ABI in
+include/memento_hip.h.  Nothing in this module has a CPU fallback.
+"""
+
+import ctypes
+from ctypes import c_void_p
+
+import numpy as np
+
+from . import _lib
+
+BLOCK_CELLS = 8192
+MAX_COUNT = (1 << 19) - 1
+ORDER_SMALL_CAP = 1024
+ORDER_BIG_CAP = 8192
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _stream():
+    return c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def dev(a, dtype=None):
+    """numpy -> device tensor (contiguous)."""
+    torch = _torch()
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if a.dtype == np.uint64:  # torch has limited uint64 support: ship the bits as int64
+        return torch.from_numpy(a.view(np.int64)).cuda()
+    if a.dtype == np.uint32:
+        return torch.from_numpy(a.view(np.int32)).cuda()
+    if a.dtype == np.uint16:
+        return torch.from_numpy(a.view(np.int16)).cuda()
+    return torch.from_numpy(a).cuda()
+
+
+def empty(shape, dtype):
+    torch = _torch()
+    return torch.empty(shape, dtype=dtype, device="cuda")
+
+
+def zeros(shape, dtype):
+    torch = _torch()
+    return torch.zeros(shape, dtype=dtype, device="cuda")
+
+
+def P(t):
+    """device pointer of a tensor (or NULL)."""
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def host(t, dtype=None):
+    a = t.cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+class DeviceCSR:
+    """The user's CSR on the device: indptr int64, indices int32, data float32 (integer-valued counts)."""
+
+    def __init__(self, X):
+        import scipy.sparse as sp
+
+        if not sp.isspmatrix_csr(X):
+            raise TypeError("X must be a scipy.sparse.csr_matrix")
+        if not X.has_canonical_format:
+            X = X.copy()
+            X.sum_duplicates()
+        self.shape = X.shape
+        self.nnz = int(X.nnz)
+        data = X.data
+        if data.dtype != np.float32:
+            d32 = data.astype(np.float32)
+            if not np.array_equal(d32.astype(data.dtype), data):
+                raise ValueError("count matrix values are not exactly representable in float32")
+            data = d32
+        self.indptr = dev(X.indptr, np.int64)
+        self.indices = dev(X.indices, np.int32)
+        self.data = dev(data, np.float32)
+
+    @property
+    def nbytes(self):
+        return self.indptr.numel() * 8 + self.indices.numel() * 4 + self.data.numel() * 4
+
+    def rowsum(self, gene_mask=None):
+        """K3: per-cell sums, optionally over a gene mask (estimator.py:65, :73)."""
+        torch = _torch()
+        out = empty((self.shape[0],), torch.float64)
+        m = dev(np.asarray(gene_mask, dtype=np.uint8)) if gene_mask is not None else None
+        _lib.call("mm_csr_rowsum", P(self.indptr), P(self.indices), P(self.data), self.shape[0], P(m), P(out), _stream())
+        return host(out)
+
+
+def plan_blocks(group_id, n_groups, block_cells=BLOCK_CELLS):
+    """Order cells by group (stable) and cut every group into near-equal blocks of <= block_cells.
+
+    Returns cell_order, blk_cell0 (nb+1), blk_group (nb), grp_blk0 (n_groups+1), grp_ncells."""
+    group_id = np.asarray(group_id)
+    sel = np.flatnonzero(group_id >= 0)
+    order = sel[np.argsort(group_id[sel], kind="stable")].astype(np.int32)
+    counts = np.bincount(group_id[sel], minlength=n_groups).astype(np.int64)
+    blk_cell0, blk_group, grp_blk0 = [0], [], [0]
+    pos = 0
+    for g in range(n_groups):
+        n = int(counts[g])
+        nb = max(1, -(-n // block_cells)) if n > 0 else 0
+        for k in range(nb):
+            pos_end = pos + (n * (k + 1)) // nb - (n * k) // nb
+            blk_group.append(g)
+            blk_cell0.append(pos_end)
+            pos = pos_end
+        grp_blk0.append(len(blk_group))
+    return (order, np.asarray(blk_cell0, dtype=np.int32), np.asarray(blk_group, dtype=np.int32),
+            np.asarray(grp_blk0, dtype=np.int32), counts)
+
+
+class CountBlocks:
+    """K0 result: the group-ordered SELL-64x4 count blocks living in HBM (see include/memento_hip.h)."""
+
+    def __init__(self, csr, group_id, n_groups):
+        torch = _torch()
+        self.G = int(csr.shape[1])
+        self.n_groups = int(n_groups)
+        (self.cell_order, self.blk_cell0, self.blk_group, self.grp_blk0, self.grp_ncells) = plan_blocks(group_id, n_groups)
+        nb = self.n_blocks = len(self.blk_group)
+        G = self.G
+        self.n_slices = (G + 63) // 64
+        ns = self.n_slices
+        s = _stream()
+        self.d_cell_order = dev(self.cell_order)
+        self.d_blk_cell0 = dev(self.blk_cell0)
+        self.d_blk_group = dev(self.blk_group)
+        self.d_grp_blk0 = dev(self.grp_blk0)
+        blk_cnt = zeros((nb, G), torch.int16)
+        status = zeros((1,), torch.int32)
+        _lib.call("mm_sell_count", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
+                  P(blk_cnt), P(status), s)
+        if int(status.item()) != 0:
+            raise ValueError(f"count matrix must hold positive integer counts <= {MAX_COUNT} with valid column indices")
+        self.rank = empty((nb, G), torch.int32)
+        self.perm = empty((nb, ns * 64), torch.int32)
+        self.slice_w = empty((nb, ns), torch.int32)
+        self.slice_ptr = empty((nb, ns + 1), torch.int32)
+        self.item_ptr = empty((nb, ns + 1), torch.int32)
+        blk_rows = empty((nb,), torch.int64)
+        blk_items = empty((nb,), torch.int32)
+        _lib.call("mm_sell_layout", P(blk_cnt), nb, G, P(self.rank), P(self.perm), P(self.slice_w), P(self.slice_ptr),
+                  P(self.item_ptr), P(blk_rows), P(blk_items), s)
+        rows = host(blk_rows)
+        items = host(blk_items).astype(np.int64)
+        base = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+        ibase = np.concatenate([[0], np.cumsum(items)]).astype(np.int64)
+        self.total_rows = int(base[-1])
+        self.total_items = int(ibase[-1])
+        self.blk_base = dev(base[:-1])
+        self.blk_item_base = dev(ibase[:-1])
+        self.ent = zeros((max(1, self.total_rows) * 256,), torch.int32)
+        _lib.call("mm_sell_scatter", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
+                  P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), s)
+        self.nnz_sel = int(host(blk_cnt, np.uint16).astype(np.int64).sum())
+        del blk_cnt
+        # slab for K1 partial sums (reused across calls)
+        n = max(1, self.total_items) * 64
+        self._S = [empty((n,), torch.float64) for _ in range(3)]
+        self._SX = empty((n,), torch.int32)
+        self._MX = empty((n,), torch.int32)
+
+    @property
+    def ent_bytes(self):
+        return self.total_rows * 1024
+
+    def moments_bytes(self):
+        """Algorithmic HBM bytes of one mm_moments1d_sell launch on this layout: the packed entries (4 B each
+        incl. the slice padding actually stored), per-item pointers, the staged 1/sf and the slab written."""
+        return (self.total_rows * 1024 + self.n_blocks * (self.n_slices * 12 + 8) + len(self.cell_order) * 8
+                + self.total_items * 64 * 32)
+
+    def launch_moments(self, d_inv_sf):
+        """Enqueue only the K1 kernel (used by bench.py to time the roofline kernel)."""
+        _lib.call("mm_moments1d_sell", P(self.ent), P(self.blk_base), P(self.slice_w), P(self.slice_ptr), P(self.item_ptr),
+                  P(self.blk_item_base), P(self.d_blk_cell0), P(d_inv_sf), self.n_blocks, self.G, P(self._S[0]), P(self._S[1]),
+                  P(self._S[2]), P(self._SX), P(self._MX), _stream())
+
+    def moments(self, inv_sf_cells):
+        """K1+K2.  ``inv_sf_cells``: 1/size_factor per ORIGINAL cell index.  Returns host arrays
+        S (3, n_groups, G) float64, sumx (n_groups, G) uint64, maxx (n_groups, G) uint32."""
+        torch = _torch()
+        d_inv = dev(np.asarray(inv_sf_cells, dtype=np.float64)[self.cell_order])
+        self.launch_moments(d_inv)
+        out_S = empty((3, self.n_groups, self.G), torch.float64)
+        out_sx = empty((self.n_groups, self.G), torch.int64)
+        out_mx = empty((self.n_groups, self.G), torch.int32)
+        _lib.call("mm_moments1d_reduce", P(self._S[0]), P(self._S[1]), P(self._S[2]), P(self._SX), P(self._MX), P(self.rank),
+                  P(self.item_ptr), P(self.blk_item_base), P(self.d_grp_blk0), self.n_groups, self.G, P(out_S), P(out_sx),
+                  P(out_mx), _stream())
+        return host(out_S), host(out_sx, np.uint64), host(out_mx, np.uint32)
+
+
+def pcg64_state(seed=5):
+    """(state_hi, state_lo, inc_hi, inc_lo) of np.random.PCG64(seed) -- what bootstrap.py:102 constructs."""
+    st = np.random.PCG64(seed).state["state"]
+    m = (1 << 64) - 1
+    return (ctypes.c_uint64 * 4)(st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m)
+
+
+class Bootstrap1D:
+    """K5 -> K8 for a set of tested genes: histograms, bins, replay order, replay bootstrap, fill+log.
+
+    After ``run`` the device holds ym/yv [n_pairs][B+1] (pair = gene_slot*n_groups + group; column 0 =
+    log true mean / log true residual variance) ready for the contraction kernel.
+    """
+
+    def __init__(self, blocks, gene_idx, maxx, sf_bin_cells, sf_table, grp_q, num_boot):
+        torch = _torch()
+        self.blocks = blocks
+        self.ng = blocks.n_groups
+        self.gene_idx = np.asarray(gene_idx, dtype=np.int64)
+        self.n_tested = len(self.gene_idx)
+        self.n_pairs = self.n_tested * self.ng
+        self.B = int(num_boot)
+        self.ld = self.B + 1
+        self.n_bins = int(len(sf_table))
+        if self.n_bins > 256:
+            raise ValueError("at most 256 size-factor bins are supported")
+        self.sf_table = np.asarray(sf_table, dtype=np.float64)
+        self.grp_q = np.asarray(grp_q, dtype=np.float64)
+        s = _stream()
+        b = blocks
+        # per (group, sf_bin) cell counts (the zero-count bins come from these)
+        bins_sorted = np.asarray(sf_bin_cells, dtype=np.uint8)[b.cell_order]
+        grp_of_sorted = np.repeat(np.arange(self.ng), b.grp_ncells)
+        self.grp_bin_cells = np.zeros((self.ng, self.n_bins), dtype=np.uint32)
+        np.add.at(self.grp_bin_cells, (grp_of_sorted, bins_sorted), 1)
+        d_bins = dev(bins_sorted)
+        pairbase = np.full(b.G, -1, dtype=np.int32)
+        pairbase[self.gene_idx] = (np.arange(self.n_tested) * self.ng).astype(np.int32)
+        xcap = (np.asarray(maxx, dtype=np.int64)[:, self.gene_idx].T.reshape(-1) + 1).astype(np.int32)  # [pair]
+        tab_ptr = np.concatenate([[0], np.cumsum(xcap.astype(np.int64) * self.n_bins)]).astype(np.int64)
+        self.d_xcap, self.d_tab_ptr = dev(xcap), dev(tab_ptr[:-1])
+        self.tab = zeros((max(1, int(tab_ptr[-1])),), torch.int32)
+        d_pairbase = dev(pairbase)  # NB: every device operand must stay referenced until after the call
+        _lib.call("mm_hist1d_sell", P(b.ent), P(b.blk_base), P(b.slice_w), P(b.slice_ptr), P(b.item_ptr), P(b.perm),
+                  P(b.d_blk_cell0), P(b.d_blk_group), P(d_bins), b.n_blocks, b.G, P(d_pairbase), P(self.d_tab_ptr),
+                  P(self.d_xcap), P(self.tab), s)
+        self.d_K = empty((self.n_pairs,), torch.int32)
+        d_gbc = dev(self.grp_bin_cells)
+        _lib.call("mm_bins_count", P(self.tab), P(self.d_tab_ptr), P(self.d_xcap), self.n_pairs, self.ng, self.n_bins,
+                  P(d_gbc), P(self.d_K), s)
+        self.K = host(self.d_K)
+        self.xcap, self.tab_ptr = xcap, tab_ptr
+
+    def bins_of_pair(self, p):
+        """Debug/test helper: the canonical (sf_bin, count, multiplicity) bins of pair p (host arrays)."""
+        t0, xc = int(self.tab_ptr[p]), int(self.xcap[p])
+        tab = host(self.tab[t0:t0 + self.n_bins * xc], np.uint32).reshape(self.n_bins, xc)
+        bi, xi = np.nonzero(tab)
+        return bi, xi, tab[bi, xi]
+
+    def run(self, skip, r1, r0, true_mean_log, true_rv_log, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5):
+        """``skip``[pair] bool; ``r1``/``r0``[pair] the two uniforms of bootstrap.py:62,65; column-0 logs per pair.
+        Returns n_invalid [n_pairs][2] (host).  Leaves self.ym / self.yv on the device."""
+        torch = _torch()
+        s = _stream()
+        ng, B, ld = self.ng, self.B, self.ld
+        active = (~np.asarray(skip, dtype=bool)) & (self.K >= 2)
+        act = np.flatnonzero(active)
+        if (self.K[act] > ORDER_BIG_CAP).any():
+            raise NotImplementedError(f"a (gene, group) pair has more than {ORDER_BIG_CAP} unique bins")
+        order = act[np.argsort(-self.K[act], kind="stable")]
+        n_act = len(order)
+        n_tiles = (n_act + 63) // 64
+        self.n_tiles = n_tiles
+        pair_slot = np.full(self.n_pairs, -1, dtype=np.int64)
+        pair_slot[order] = np.arange(n_act)
+        slot_pair = np.full(n_tiles * 64, -1, dtype=np.int64)
+        slot_pair[:n_act] = order
+        slot_K = np.zeros(n_tiles * 64, dtype=np.int32)
+        slot_K[:n_act] = self.K[order]
+        tile_k = slot_K.reshape(n_tiles, 64).max(axis=1) if n_tiles else np.zeros(0, dtype=np.int32)
+        tile_ptr = np.concatenate([[0], np.cumsum(tile_k.astype(np.int64))]).astype(np.int64)
+        rows = int(tile_ptr[-1])
+        self.draws_per_replicate = int(np.maximum(self.K[order] - 1, 0).sum())
+        ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(6)]
+        d_pair_slot, d_tile_ptr = dev(pair_slot), dev(tile_ptr)
+        status = zeros((1,), torch.int32)
+        d_r1, d_r0 = dev(np.asarray(r1, dtype=np.float64)), dev(np.asarray(r0, dtype=np.float64))
+        d_sf, d_nc, d_q = dev(self.sf_table), dev(self.blocks.grp_ncells.astype(np.float64)), dev(self.grp_q)
+        small = order[self.K[order] <= ORDER_SMALL_CAP]
+        big = order[self.K[order] > ORDER_SMALL_CAP]
+        for lst, is_big in ((small, 0), (big, 1)):
+            if len(lst):
+                d_lst = dev(lst)
+                _lib.call("mm_bins_order", P(self.tab), P(self.d_tab_ptr), P(self.d_xcap), P(self.d_K), P(d_lst), len(lst),
+                          is_big, ng, self.n_bins, P(d_sf), P(d_r1), P(d_r0), P(d_pair_slot), P(d_tile_ptr), P(d_nc), P(d_q),
+                          *[P(o) for o in ops], P(status), s)
+        nobs = np.zeros(n_tiles * 64, dtype=np.float64)
+        nobs[:n_act] = self.blocks.grp_ncells[order % ng]
+        self.ym = torch.full((self.n_pairs, ld), float("nan"), dtype=torch.float64, device="cuda")
+        self.yv = torch.full((self.n_pairs, ld), float("nan"), dtype=torch.float64, device="cuda")
+        self.ym[:, 0] = dev(np.asarray(true_mean_log, dtype=np.float64))
+        self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
+        kmax_dump = int(tile_k.max()) if (dump_weights and n_tiles) else 0
+        self.w_dump = zeros((n_tiles * 64, kmax_dump, B), torch.int32) if dump_weights else None
+        self.kmax_dump = kmax_dump
+        self.slot_pair, self.slot_K, self.pair_slot, self.tile_ptr = slot_pair, slot_K, pair_slot, tile_ptr
+        self.ops = ops
+        d_slot_K, d_nobs, d_slot_pair = dev(slot_K), dev(nobs), dev(slot_pair)
+        if n_tiles:
+            _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_slot_pair),
+                      pcg64_state(pcg_seed), B, ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, s)
+        st = int(status.item())
+        if st & 2 or st & 4:
+            raise RuntimeError(f"mm_bins_order inconsistency (status {st})")
+        if st & 8:
+            raise NotImplementedError("two bins of one pair collided in the replay hash (np.unique would merge them)")
+        self.raw_mean = self.ym.clone() if dump_weights else None
+        self.raw_var = self.yv.clone() if dump_weights else None
+        n_inv = empty((self.n_pairs, 2), torch.int32)
+        fit = (ctypes.c_double * 3)(*[float(x) for x in mv_fit])
+        _lib.call("mm_boot_fill_log", P(self.ym), P(self.yv), self.n_pairs, ld, B, fit, int(fill_mode), int(fill_seed) & ((1 << 64) - 1),
+                  P(n_inv), s)
+        self.active = active
+        return host(n_inv)
+
+    def contract(self, test_gene, W, good, which):
+        """K9+K10 for tests (gene slot, weight row).  Returns (coef device tensor [n_tests][ld], stats host [n_tests][8])."""
+        torch = _torch()
+        n_tests = len(test_gene)
+        coef = empty((max(1, n_tests), self.ld), torch.float64)
+        stats = empty((max(1, n_tests), 8), torch.float64)
+        d_tg, d_W, d_good = dev(np.asarray(test_gene, dtype=np.int32)), dev(np.asarray(W, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
+        _lib.call("mm_contract_stats", P(self.ym), P(self.yv), self.ld, self.B, self.ng, P(d_tg), P(d_W), P(d_good), n_tests,
+                  int(which), P(coef), P(stats), _stream())
+        return coef, host(stats)[:n_tests]

@@ -1,0 +1,84 @@
+"""csrc/npy_rng.h (the product's PCG64 + binomial + multinomial restatement) compiled for the HOST and
+compared draw-for-draw with numpy's Generator(PCG64) -- the third-party implementation the reference
+calls (bootstrap.py:102-103).  CPU only."""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    out = tmp_path_factory.mktemp("shim") / "libnpyrng_host.so"
+    src = os.path.join(ROOT, "tests", "host_shim", "npy_rng_host.cpp")
+    inc = os.path.join(ROOT, "scrna_parameter_estimation_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I", inc, src, "-o", str(out)])
+    return ctypes.CDLL(str(out))
+
+
+def pcg_state(seed):
+    s = np.random.PCG64(seed).state["state"]
+    m = (1 << 64) - 1
+    return (ctypes.c_uint64 * 4)(s["state"] >> 64, s["state"] & m, s["inc"] >> 64, s["inc"] & m)
+
+
+def test_pcg64_pins(shim):
+    # pins recorded in SURVEY.md section 8c for PCG64(5)
+    out = (ctypes.c_uint64 * 4)()
+    shim.host_pcg64_raw(pcg_state(5), 4, out)
+    assert list(out) == [14849682912918955432, 14903876974979881461, 9506078739185184192, 5272104914398938230]
+    ref = np.random.PCG64(5).random_raw(4)
+    assert list(out) == list(ref)
+
+
+@pytest.mark.parametrize("n,p", [(20, 0.1), (50000, 0.9), (7, 0.5), (100000, 0.0002), (100000, 0.03), (300, 0.4),
+                                 (12345, 0.5), (1 << 40, 1e-9), (1 << 33, 0.25), (3, 0.99)])
+def test_binomial_matches_numpy(shim, n, p):
+    cnt = 4000
+    out = np.zeros(cnt, dtype=np.int64)
+    shim.host_binomial(pcg_state(5), ctypes.c_double(p), ctypes.c_int64(n), cnt, out.ctypes.data_as(ctypes.c_void_p))
+    ref = np.random.Generator(np.random.PCG64(5)).binomial(n, p, cnt)
+    np.testing.assert_array_equal(out, ref)
+
+
+def _multi(shim, seed, n, pv, B):
+    d = len(pv)
+    out = np.zeros((B, d), dtype=np.int64)
+    pv = np.ascontiguousarray(pv, dtype=np.float64)
+    shim.host_multinomial(pcg_state(seed), ctypes.c_int64(n), pv.ctypes.data_as(ctypes.c_void_p), d, B,
+                          out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def test_multinomial_pins(shim):
+    np.testing.assert_array_equal(_multi(shim, 5, 10, [.2, .3, .5], 4), [[3, 4, 3], [2, 2, 6], [0, 3, 7], [2, 1, 7]])
+    np.testing.assert_array_equal(_multi(shim, 5, 50000, [.9, .05, .03, .02], 3),
+                                  [[44942, 2552, 1477, 1029], [45134, 2385, 1508, 973], [44995, 2439, 1515, 1051]])
+
+
+def test_multinomial_random_shapes(shim):
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        d = int(rng.integers(2, 200))
+        # scRNA-like multiplicities: a few huge zero-count bins, many small ones
+        mult = np.concatenate([rng.integers(1, 5000, size=max(1, d // 4)), rng.integers(1, 40, size=d - max(1, d // 4))])
+        rng.shuffle(mult)
+        n = int(mult.sum()) if trial % 3 else int(rng.integers(1, 10 ** 6))
+        pv = mult / mult.sum()
+        B = 50
+        got = _multi(shim, 5, n, pv, B)
+        ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
+        np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial} d={d} n={n}")
+
+
+def test_multinomial_golden_weights(shim, internals_small):
+    it = internals_small
+    for k in range(int(it["n_picks"])):
+        mult = it[f"p{k}_counts"]
+        got = _multi(shim, 5, int(it[f"p{k}_n_obs"]), mult / mult.sum(), int(it["num_boot"]))
+        np.testing.assert_array_equal(got.T, it[f"p{k}_weights"])
