@@ -262,15 +262,27 @@ class Bootstrap1D:
         bi, xi = np.nonzero(tab)
         return bi, xi, tab[bi, xi]
 
-    def run(self, skip, r1, r0, true_mean_log, true_rv_log, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5):
-        """``skip``[pair] bool; ``r1``/``r0``[pair] the two uniforms of bootstrap.py:62,65; column-0 logs per pair.
-        Returns n_invalid [n_pairs][2] (host).  Leaves self.ym / self.yv on the device."""
+    def alloc_outputs(self, true_mean_log, true_rv_log):
+        """ym/yv [n_pairs][B+1] = NaN, column 0 = log true mean / log true residual variance (hypothesis_test.py:174)."""
+        torch = _torch()
+        self.ym = torch.full((self.n_pairs, self.ld), float("nan"), dtype=torch.float64, device="cuda")
+        self.yv = torch.full((self.n_pairs, self.ld), float("nan"), dtype=torch.float64, device="cuda")
+        self.ym[:, 0] = dev(np.asarray(true_mean_log, dtype=np.float64))
+        self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
+
+    def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0):
+        """Order bins, replay the bootstrap and fill/log for every pair >= ``first_pair`` that is not skipped.
+
+        ``skip``[pair] bool; ``r1``/``r0``[pair] the two uniforms of bootstrap.py:62,65.  Rows below
+        ``first_pair`` are left untouched (used by the strict replay driver).  Returns n_invalid
+        [n_pairs - first_pair][2] (host): invalid (mean, res_var) replicates per row, -1 = no valid one."""
         torch = _torch()
         s = _stream()
         ng, B, ld = self.ng, self.B, self.ld
         active = (~np.asarray(skip, dtype=bool)) & (self.K >= 2)
+        active[:first_pair] = False
         act = np.flatnonzero(active)
-        if (self.K[act] > ORDER_BIG_CAP).any():
+        if len(act) and (self.K[act] > ORDER_BIG_CAP).any():
             raise NotImplementedError(f"a (gene, group) pair has more than {ORDER_BIG_CAP} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         n_act = len(order)
@@ -301,15 +313,10 @@ class Bootstrap1D:
                           *[P(o) for o in ops], P(status), s)
         nobs = np.zeros(n_tiles * 64, dtype=np.float64)
         nobs[:n_act] = self.blocks.grp_ncells[order % ng]
-        self.ym = torch.full((self.n_pairs, ld), float("nan"), dtype=torch.float64, device="cuda")
-        self.yv = torch.full((self.n_pairs, ld), float("nan"), dtype=torch.float64, device="cuda")
-        self.ym[:, 0] = dev(np.asarray(true_mean_log, dtype=np.float64))
-        self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
         kmax_dump = int(tile_k.max()) if (dump_weights and n_tiles) else 0
         self.w_dump = zeros((n_tiles * 64, kmax_dump, B), torch.int32) if dump_weights else None
         self.kmax_dump = kmax_dump
         self.slot_pair, self.slot_K, self.pair_slot, self.tile_ptr = slot_pair, slot_K, pair_slot, tile_ptr
-        self.ops = ops
         d_slot_K, d_nobs, d_slot_pair = dev(slot_K), dev(nobs), dev(slot_pair)
         if n_tiles:
             _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_slot_pair),
@@ -321,12 +328,14 @@ class Bootstrap1D:
             raise NotImplementedError("two bins of one pair collided in the replay hash (np.unique would merge them)")
         self.raw_mean = self.ym.clone() if dump_weights else None
         self.raw_var = self.yv.clone() if dump_weights else None
-        n_inv = empty((self.n_pairs, 2), torch.int32)
+        n_rows = self.n_pairs - first_pair
+        n_inv = empty((max(1, n_rows), 2), torch.int32)
         fit = (ctypes.c_double * 3)(*[float(x) for x in mv_fit])
-        _lib.call("mm_boot_fill_log", P(self.ym), P(self.yv), self.n_pairs, ld, B, fit, int(fill_mode), int(fill_seed) & ((1 << 64) - 1),
-                  P(n_inv), s)
+        if n_rows > 0:
+            _lib.call("mm_boot_fill_log", c_void_p(self.ym.data_ptr() + first_pair * ld * 8), c_void_p(self.yv.data_ptr() + first_pair * ld * 8),
+                      n_rows, ld, B, fit, int(fill_mode), int(fill_seed) & ((1 << 64) - 1), P(n_inv), s)
         self.active = active
-        return host(n_inv)
+        return host(n_inv)[:n_rows]
 
     def contract(self, test_gene, W, good, which):
         """K9+K10 for tests (gene slot, weight row).  Returns (coef device tensor [n_tests][ld], stats host [n_tests][8])."""

@@ -1,0 +1,458 @@
+"""Public API: the same names, arguments and ``adata.uns['memento']`` schema as the reference's
+``memento/main.py`` -- with the hot path running in hand-written HIP kernels (no CPU fallback).
+
+Reference signatures mirrored (paths relative to /root/reference/):
+  setup_memento        memento/main.py:26-34      create_groups      :94-99
+  compute_1d_moments   :171-176                   ht_1d_moments      :341-350
+  get_groups           :156-168                   get_1d_moments / get_1d_ht_result  :523, :635
+Extra keyword-only knobs (do not disturb the reference's positional order):
+  ht_1d_moments(..., rng='replay', strict=False, fill_seed=0)
+  compute_1d_moments(..., subset_var=True)
+
+Host code here is argument handling, the uns schema, O(G) post-processing (polyfit, filters, design
+matrix, p-values); every O(nnz) or O(G x groups x B) step is a kernel launch via ``engine``.
+"""
+
+import itertools
+
+import numpy as np
+import pandas as pd
+import scipy.stats as stats
+from scipy.sparse import csr_matrix
+
+from .. import engine
+from . import asl as _asl
+from . import design as _design
+
+
+# ----------------------------------------------------------------------------------------------
+# state kept next to the AnnData (device handles are not serialisable: prepare_to_save drops them)
+# ----------------------------------------------------------------------------------------------
+
+
+class _HipState:
+    """Device-resident data of one AnnData: CSR, count blocks, per-(group, gene) integer sums."""
+
+    def __init__(self):
+        self.csr = None
+        self.blocks = None
+        self.sumx = None
+        self.maxx = None
+        self.gene_idx = None  # original column index of every currently kept gene
+
+    def __deepcopy__(self, memo):  # shared, read-only after construction
+        return self
+
+
+class _GroupCellsView:
+    """Stands in for the reference's per-group CSC copy (main.py:128): only ``shape`` is ever read
+    by the API (main.py:364, :534); the counts themselves live in the device count blocks."""
+
+    def __init__(self, n_cells, n_genes):
+        self.shape = (int(n_cells), int(n_genes))
+
+    def __repr__(self):
+        return f"<device count-block view {self.shape[0]} cells x {self.shape[1]} genes>"
+
+
+def _mv_fit(mean, var):
+    """np.polyfit(log m, log v, 2) over m>0 & v>0  (estimator.py:84-93)."""
+    ok = (mean > 0) & (var > 0)
+    return np.polyfit(np.log(mean[ok]), np.log(var[ok]), 2)
+
+
+def _res_var(mean, var, fit):
+    """estimator.py:103-111."""
+    ok = (mean > 0) & (var > 0)
+    out = np.full(mean.shape, np.nan)
+    with np.errstate(invalid="ignore"):
+        out[ok] = np.exp(np.log(var[ok]) - np.poly1d(fit)(np.log(mean[ok])))
+    return out
+
+
+def _moments_from_sums(S, n_obs, q):
+    """mean = S1/n ; var = S2/n - (1-q) S3/n - mean^2   (estimator.py:179-183)."""
+    mean = S[0] / n_obs
+    var = S[1] / n_obs - (1 - q) * S[2] / n_obs - mean ** 2
+    return mean, var
+
+
+# ----------------------------------------------------------------------------------------------
+# setup_memento / create_groups
+# ----------------------------------------------------------------------------------------------
+
+
+def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_percent=0.1, shrinkage=0.5, num_bins=30,
+                  estimator_type='hyper_relative'):
+    """Compute size factors and the all-cell moments (reference: memento/main.py:26-91)."""
+    if not inplace:
+        adata = adata.copy()
+    assert adata.obs[q_column].max() < 1
+    assert type(adata.X) == csr_matrix, 'please make sure that adata.X is a scipy CSR matrix'
+    if estimator_type != 'hyper_relative':
+        raise NotImplementedError("the HIP path implements estimator_type='hyper_relative'")
+    m = adata.uns['memento'] = {}
+    m['q_column'] = q_column
+    m['all_q'] = adata.obs[q_column].values.mean()
+    m['estimator_type'] = estimator_type
+    m['filter_mean_thresh'] = filter_mean_thresh
+    m['num_bins'] = num_bins
+
+    st = m['_hip'] = _HipState()
+    st.csr = engine.DeviceCSR(adata.X)
+    N, G = adata.shape
+    st.gene_idx = np.arange(G)
+    naive = st.csr.rowsum()                                                   # estimator.py:64-69
+    blocks_all = engine.CountBlocks(st.csr, np.zeros(N, dtype=np.int32), 1)
+    with np.errstate(divide="ignore"):
+        S, sumx, _ = blocks_all.moments(1.0 / naive)
+    all_m, all_v = _moments_from_sums(S[:, 0], N, m['all_q'])                 # main.py:62-66
+    all_m = all_m.copy()
+    all_m[(sumx[0].astype(np.float64) / N) < filter_mean_thresh] = 0          # main.py:67
+    all_rv = _res_var(all_m, all_v, _mv_fit(all_m, all_v))                    # main.py:68
+    rv_ulim = np.quantile(all_rv[np.isfinite(all_rv)], trim_percent)          # main.py:71
+    all_rv[~np.isfinite(all_rv)] = np.inf
+    mask = all_rv < rv_ulim                                                   # main.py:73
+    m['least_variable_genes'] = adata.var.index[mask].tolist()
+    nrc = st.csr.rowsum(mask)                                                 # estimator.py:73
+    nrc = nrc + np.quantile(nrc, shrinkage)                                   # estimator.py:74
+    size_factor = nrc / nrc.mean()                                            # estimator.py:75-76
+    adata.obs['memento_size_factor'] = size_factor
+    S, _, _ = blocks_all.moments(1.0 / size_factor)                           # main.py:86-90
+    m['all_1d_moments'] = list(_moments_from_sums(S[:, 0], N, m['all_q']))
+    if not inplace:
+        return adata
+
+
+def create_groups(adata, label_columns, label_delimiter='^', inplace=True):
+    """Discrete groups from obs columns; builds the group-ordered device count blocks
+    (reference: memento/main.py:94-135, util.py:8-13)."""
+    if not inplace:
+        adata = adata.copy()
+    m = adata.uns['memento']
+    lab = 'sg' + label_delimiter
+    for idx, col_name in enumerate(label_columns):
+        lab = lab + adata.obs[col_name].astype(str)
+        if idx != len(label_columns) - 1:
+            lab = lab + label_delimiter
+    adata.obs['memento_group'] = lab
+    m['label_columns'] = label_columns
+    m['label_delimiter'] = label_delimiter
+    codes, uniques = pd.factorize(adata.obs['memento_group'].values)          # first-appearance order == drop_duplicates
+    m['groups'] = list(uniques)
+    m['q'] = adata.obs[m['q_column']].values
+    st = m['_hip']
+    st.group_id = codes.astype(np.int32)
+    st.blocks = engine.CountBlocks(st.csr, st.group_id, len(uniques))
+    G = adata.shape[1]
+    m['group_cells'] = {g: _GroupCellsView(st.blocks.grp_ncells[i], G) for i, g in enumerate(m['groups'])}
+    qsum = np.bincount(codes, weights=m['q'], minlength=len(uniques))
+    m['group_q'] = {g: qsum[i] / st.blocks.grp_ncells[i] for i, g in enumerate(m['groups'])}
+    for k in ('size_factor', 'approx_size_factor', 'all_approx_size_factor'):
+        m.pop(k, None)
+    if not inplace:
+        return adata
+
+
+def _bin_size_factor(adata):
+    """30 equal-width bins over all cells' size factors; cell -> bin mean; the max keeps its own value
+    (reference: memento/main.py:138-153).  Also records the integer bin id per cell for the device."""
+    m = adata.uns['memento']
+    size_factor = adata.obs['memento_size_factor'].values
+    means, _, idx = stats.binned_statistic(size_factor, size_factor, bins=m['num_bins'], statistic='mean')
+    idx = np.clip(idx, a_min=1, a_max=means.shape[0]) - 1
+    max_sf = size_factor.max()
+    is_max = size_factor == max_sf
+    table = np.concatenate([means, [max_sf]])            # one extra "bin" for the max cell(s)
+    bin_id = idx.astype(np.int64)
+    bin_id[is_max] = means.shape[0]
+    approx_sf = table[bin_id]
+    st = m['_hip']
+    st.sf_bin = bin_id.astype(np.uint8) if table.shape[0] <= 256 else None
+    st.sf_table = np.nan_to_num(table, nan=1.0)          # empty bins are never referenced
+    m['all_approx_size_factor'] = approx_sf
+    gid = st.group_id
+    m['approx_size_factor'] = {g: approx_sf[gid == i] for i, g in enumerate(m['groups'])}
+    m['size_factor'] = {g: size_factor[gid == i] for i, g in enumerate(m['groups'])}
+
+
+def get_groups(adata):
+    """DataFrame of group label components, rows in uns order (reference: memento/main.py:156-168)."""
+    m = adata.uns['memento']
+    rows = [g.split(m['label_delimiter'])[1:] for g in m['groups']]
+    df = pd.DataFrame(rows, index=m['groups'], columns=m['label_columns'])
+    for col in df.columns:
+        try:
+            df[col] = pd.to_numeric(df[col])
+        except (ValueError, TypeError):
+            pass
+    return df
+
+
+# ----------------------------------------------------------------------------------------------
+# compute_1d_moments
+# ----------------------------------------------------------------------------------------------
+
+
+def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=True, gene_list=None, subset_var=True):
+    """Mean, variance and residual variance per group (reference: memento/main.py:171-274).
+
+    ``subset_var=False`` skips the host-side column subset of ``adata`` itself (an O(nnz) scipy copy the
+    reference performs at main.py:229); the device blocks and uns['memento']['gene_list'] are what the
+    later calls use."""
+    assert 'memento' in adata.uns
+    if not inplace:
+        adata = adata.copy()
+    m = adata.uns['memento']
+    st = m['_hip']
+    if 'size_factor' not in m.keys():
+        _bin_size_factor(adata)
+    groups = m['groups']
+    ng = len(groups)
+    Nc = st.blocks.grp_ncells.astype(np.float64)
+    gq = np.array([m['group_q'][g] for g in groups])
+    S, sumx, maxx = st.blocks.moments(1.0 / adata.obs['memento_size_factor'].values)          # K1+K2
+    cur = st.gene_idx                                    # columns of the device blocks that adata currently holds
+    mean = S[0][:, cur] / Nc[:, None]
+    var = S[1][:, cur] / Nc[:, None] - (1 - gq)[:, None] * S[2][:, cur] / Nc[:, None] - mean ** 2
+    st.sumx, st.maxx = sumx, maxx
+    obs_mean = sumx[:, cur].astype(np.float64) / Nc[:, None]                                   # main.py:201
+    gene_filter = (obs_mean > m['filter_mean_thresh']) & (var > 0)                             # main.py:202-203
+    gene_rv_filter = maxx[:, cur] >= 2                                                         # main.py:206-207
+    m['gene_filter'] = {g: gene_filter[i] for i, g in enumerate(groups)}
+    overall = gene_filter.mean(axis=0) > min_perc_group                                        # main.py:210-212
+    m['overall_gene_filter'] = overall
+    m['gene_list'] = adata.var.index[overall].tolist()
+    if filter_genes:                                                                           # main.py:219-229
+        mean, var, gene_rv_filter = mean[:, overall], var[:, overall], gene_rv_filter[:, overall]
+        st.gene_idx = cur[overall]
+        for g in groups:
+            m['group_cells'][g] = _GroupCellsView(m['group_cells'][g].shape[0], int(overall.sum()))
+        if subset_var:
+            adata._inplace_subset_var(overall)
+        else:
+            st.var_names = np.asarray(adata.var.index)[overall]
+    m['gene_rv_filter'] = {g: gene_rv_filter[i] for i, g in enumerate(groups)}
+    fit = _mv_fit(np.concatenate([mean[i][gene_rv_filter[i]] for i in range(ng)]),
+                  np.concatenate([var[i][gene_rv_filter[i]] for i in range(ng)]))              # main.py:232-245
+    m['mv_regressor'] = {'all': fit}
+    for g in groups:
+        m['mv_regressor'][g] = fit
+    m['1d_moments'] = {g: [mean[i], var[i], _res_var(mean[i], var[i], fit)] for i, g in enumerate(groups)}  # main.py:248-255
+    if gene_list is not None:                                                                  # main.py:258-271
+        assert type(gene_list) == list
+        names = _var_names(adata)
+        given = np.in1d(names, gene_list)
+        for g in groups:
+            m['1d_moments'][g] = [a[given] for a in m['1d_moments'][g]]
+            m['group_cells'][g] = _GroupCellsView(m['group_cells'][g].shape[0], int(given.sum()))
+        st.gene_idx = st.gene_idx[given]
+        if subset_var:
+            adata._inplace_subset_var(given)
+        else:
+            st.var_names = names[given]
+    if not inplace:
+        return adata
+
+
+def _var_names(adata):
+    st = adata.uns['memento']['_hip']
+    names = getattr(st, 'var_names', None)
+    if names is not None and len(names) == len(st.gene_idx):
+        return np.asarray(names)
+    return np.asarray(adata.var.index)
+
+
+# ----------------------------------------------------------------------------------------------
+# ht_1d_moments
+# ----------------------------------------------------------------------------------------------
+
+
+def _pair_skip(true_mean, true_rv):
+    """hypothesis_test.py:167-171, vectorised over [n_groups][G] -> [pair] (gene-major)."""
+    with np.errstate(invalid="ignore"):
+        skip = np.isnan(true_mean) | np.isnan(true_rv) | (true_mean == 0) | (true_rv < 0)
+    return skip.T.reshape(-1)
+
+
+def _host_fill(row):
+    """hypothesis_test._fill on an already-logged row: NaN = invalid; draws from the global np.random
+    stream exactly like np.random.choice(val[~cond], num_invalid) (hypothesis_test.py:23-33)."""
+    bad = np.isnan(row)
+    nbad = int(bad.sum())
+    if nbad == row.shape[0]:
+        return None
+    row = row.copy()
+    row[bad] = np.random.choice(row[~bad], nbad)
+    return row
+
+
+def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=1, num_cpus=1,
+                  rng='replay', strict=False, fill_seed=0, **kwargs):
+    """Bootstrap hypothesis test of mean / residual-variance differences (reference: memento/main.py:341-415).
+
+    ``rng='replay'``: the multinomial resampling replays numpy's ``Generator(PCG64(5))`` stream draw for
+    draw (bootstrap.py:102-103) and the bin order uses the two uniforms the reference takes from the global
+    ``np.random`` state per (gene, group) (bootstrap.py:62, :65).
+    ``strict=True`` additionally replays the reference's ``_fill`` draws from the global stream in gene order
+    (exactly reproducible against the reference at ``num_cpus=1``; sequential, meant for validation);
+    with ``strict=False`` invalid replicates are re-filled on the device with a counter-based RNG.
+    kwargs: ``resampling`` (required, as in the reference), ``approx``, ``resample_rep``.
+    """
+    if 'resampling' not in kwargs:
+        raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
+    if kwargs['resampling'] != 'bootstrap':
+        raise NotImplementedError("only resampling='bootstrap' is implemented on the HIP path")
+    if kwargs.get('resample_rep', False):
+        raise NotImplementedError("resample_rep=True is not implemented on the HIP path yet")
+    if rng != 'replay':
+        raise NotImplementedError("rng must be 'replay'")
+    approx = bool(kwargs.get('approx', False))
+    if not inplace:
+        adata = adata.copy()
+    m = adata.uns['memento']
+    st = m['_hip']
+    groups = m['groups']
+    ng = len(groups)
+    names = _var_names(adata)
+    G = len(st.gene_idx)
+    Nc_list = np.array([m['group_cells'][g].shape[0] for g in groups], dtype=np.float64)
+    cov = np.asarray(covariate.values, dtype=np.float64)
+    trt_all = np.asarray(treatment.values, dtype=np.float64)
+    trt_cols = list(treatment.columns)
+    gq = np.array([m['group_q'][g] for g in groups])
+    true_mean = np.stack([m['1d_moments'][g][0] for g in groups])
+    true_rv = np.stack([m['1d_moments'][g][2] for g in groups])
+    fit = m['mv_regressor'][groups[0]]
+    if st.sf_bin is None:
+        raise NotImplementedError("more than 255 size-factor bins")
+
+    bs = engine.Bootstrap1D(st.blocks, st.gene_idx, st.maxx, st.sf_bin, st.sf_table, gq, num_boot)   # K5
+    skip = _pair_skip(true_mean, true_rv)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tm_log = np.where(skip, np.nan, np.log(true_mean.T.reshape(-1)))
+        tv_log = np.where(skip, np.nan, np.log(true_rv.T.reshape(-1)))
+    bs.alloc_outputs(tm_log, tv_log)
+    n_pairs = bs.n_pairs
+    r1, r0 = np.zeros(n_pairs), np.zeros(n_pairs)
+    live = np.flatnonzero(~skip)
+
+    def draw_hash(first):
+        idx = live[live >= first]
+        u = np.random.random(2 * len(idx))          # same stream positions as random(1) then random() per pair
+        r1[idx], r0[idx] = u[0::2], u[1::2]
+
+    if not strict:
+        draw_hash(0)
+        n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed)                            # K6-K8
+        bad_fill = (n_inv < 0).any(axis=1)
+    else:
+        n_inv_all = np.zeros((n_pairs, 2), dtype=np.int32)
+        first = 0
+        while first < n_pairs:
+            saved = np.random.get_state()
+            draw_hash(first)
+            n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first)
+            n_inv_all[first:] = n_inv
+            needs = np.flatnonzero((~skip[first:]) & ((n_inv > 0).any(axis=1))) + first
+            if len(needs) == 0:
+                break
+            p = int(needs[0])
+            np.random.set_state(saved)
+            np.random.random(2 * int((live >= first).sum() - (live > p).sum()))   # hash draws of pairs first..p
+            for t, col in ((bs.ym, 0), (bs.yv, 1)):
+                if n_inv_all[p, col] > 0:
+                    row = engine.host(t[p, 1:])
+                    t[p, 1:] = engine.dev(_host_fill(row))
+                    n_inv_all[p, col] = 0
+            first = p + 1
+        bad_fill = (n_inv_all < 0).any(axis=1)
+
+    active_all = (~skip) & (bs.K >= 2)                       # bootstrap.py:97-98: a single bin gives NaN replicates
+    good = (active_all & ~bad_fill).reshape(G, ng)           # hypothesis_test.py:193-200
+
+    # tests: gene-major x treatment column (main.py:399-404)
+    test_gene, test_rows = [], []
+    cache = {}
+    for gi in range(G):
+        if treatment_for_gene is None:
+            cols = None
+            nt = trt_all.shape[1]
+        else:
+            cols = [trt_cols.index(c) for c in treatment_for_gene[names[gi]]]
+            nt = len(cols)
+        key = (good[gi].tobytes(), None if cols is None else tuple(cols))
+        W = cache.get(key)
+        if W is None:
+            t = trt_all if cols is None else trt_all[:, cols]
+            W = _design.weight_rows(cov, t, Nc_list, good[gi])
+            if W.shape[0] != nt:
+                W = np.repeat(W[:1], nt, axis=0)
+            cache[key] = W
+        test_gene.extend([gi] * nt)
+        test_rows.append(W)
+    n_tests = len(test_gene)
+    Wmat = np.concatenate(test_rows, axis=0) if test_rows else np.zeros((0, ng))
+    out = {}
+    for which, tag in ((0, 'mean'), (1, 'var')):
+        coef, stt = bs.contract(test_gene, Wmat, good, which)                                         # K9+K10
+        no_group = ~good[np.asarray(test_gene, dtype=np.int64)].any(axis=1) if n_tests else np.zeros(0, bool)
+        c0, se = stt[:, 0].copy(), stt[:, 1].copy()
+        p = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
+        c0[no_group], se[no_group], p[no_group] = np.nan, np.nan, np.nan                              # hypothesis_test.py:203-204
+        out[tag + '_coef'], out[tag + '_se'], out[tag + '_asl'] = c0, se, p
+    m['1d_ht'] = {}
+    if treatment_for_gene is not None:
+        m['1d_ht']['treatment_for_gene'] = treatment_for_gene
+    m['1d_ht']['treatment'] = treatment
+    m['1d_ht']['covariate'] = covariate
+    for k in ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl'):
+        m['1d_ht'][k] = out[k]
+    st.last_bootstrap = bs
+    if not inplace:
+        return adata
+
+
+# ----------------------------------------------------------------------------------------------
+# getters
+# ----------------------------------------------------------------------------------------------
+
+
+def get_1d_moments(adata, groupby=None):
+    """log-mean / log-residual-variance tables per group (reference: memento/main.py:523-582, groupby=None form)."""
+    m = adata.uns['memento']
+    names = _var_names(adata).tolist()
+    mean_df = pd.DataFrame({'gene': names})
+    var_df = pd.DataFrame({'gene': names})
+    cell_counts = {k: v.shape[0] for k, v in m['group_cells'].items()}
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for group, val in m['1d_moments'].items():
+            mean_df[group] = np.log(val[0])
+            var_df[group] = np.log(val[2])
+    if groupby is None:
+        return mean_df, var_df, cell_counts
+    raise NotImplementedError("groupby aggregation is not implemented")
+
+
+def get_1d_ht_result(adata):
+    """DataFrame of DE / DV coefficients, standard errors and p-values (reference: memento/main.py:635-655)."""
+    ht = adata.uns['memento']['1d_ht']
+    names = _var_names(adata)
+    if 'treatment_for_gene' in ht:
+        pairs = [(g, t) for g in names for t in ht['treatment_for_gene'][g]]
+    else:
+        pairs = list(itertools.product(names, ht['treatment'].columns))
+    df = pd.DataFrame(pairs, columns=['gene', 'tx'])
+    df['de_coef'], df['de_se'], df['de_pval'] = ht['mean_coef'], ht['mean_se'], ht['mean_asl']
+    df['dv_coef'], df['dv_se'], df['dv_pval'] = ht['var_coef'], ht['var_se'], ht['var_asl']
+    return df
+
+
+def prepare_to_save(adata, keep=False):
+    """Drop objects that cannot be written to disk (reference: memento/main.py:673-683) -- here also the
+    device handles."""
+    m = adata.uns['memento']
+    m.pop('_hip', None)
+    for group in m['groups'] + ['all']:
+        m['mv_regressor'].pop(group, None)
+    m['group_cells'] = {g: v.shape for g, v in m['group_cells'].items()}

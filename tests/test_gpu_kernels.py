@@ -166,7 +166,8 @@ def test_replay_bootstrap_bit_exact(eng, orc, api_small):
     skip = np.zeros(bs.n_pairs, dtype=bool)
     skip[5] = True
     zeros = np.zeros(bs.n_pairs)
-    bs.run(skip, r1, r0, zeros, zeros, g["mv_regressor"], fill_mode=1, dump_weights=True)
+    bs.alloc_outputs(zeros, zeros)
+    bs.run(skip, r1, r0, g["mv_regressor"], fill_mode=1, dump_weights=True)
     wd = eng.host(bs.w_dump)
     rm, rv = eng.host(bs.raw_mean), eng.host(bs.raw_var)
     Xc = X.tocsc()
@@ -201,7 +202,8 @@ def test_fill_log_and_contract(eng, orc, api_small):
     tm = np.log(g["mean"].T.reshape(-1))
     tv = np.log(g["res_var"].T.reshape(-1))
     skip = ~(np.isfinite(tm) & np.isfinite(tv))
-    n_inv = bs.run(skip, r1, r0, tm, tv, g["mv_regressor"], fill_mode=1, dump_weights=True)
+    bs.alloc_outputs(tm, tv)
+    n_inv = bs.run(skip, r1, r0, g["mv_regressor"], fill_mode=1, dump_weights=True)
     rm, rv = eng.host(bs.raw_mean), eng.host(bs.raw_var)
     ym, yv = eng.host(bs.ym), eng.host(bs.yv)
     for p in range(bs.n_pairs):
