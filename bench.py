@@ -1,0 +1,287 @@
+"""bench.py -- gene-tests/s of the memento 1D hot path (compute_1d_moments + ht_1d_moments) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run, one rank
+per GPU).  One STEP = one pass of the hot path over the synthetic matrix, with the CSR and the
+group-ordered count blocks already resident in HBM:
+    compute_1d_moments  (K1 moments kernel + filters + pooled mean-variance fit)
+  + ht_1d_moments       (K5 histograms, bin ordering, numpy-replay bootstrap, fill/log, contraction,
+                         p-values incl. the host-side extreme-value tail fits)
+Multi-GPU: genes are sharded -- rank r holds all cells x its own gene shard of the same shape (weak
+scaling, no data-path collective; the pooled fit is one small all-gather).  value = gene-tests of all
+ranks / max-over-ranks time.
+
+Extra objects on the JSON line: "roofline" (the K1 kernel: algorithmic bytes / HIP-event time vs 8 TB/s),
+"bootstrap" (binomial draws/s of the replay kernel), "cpu_baseline" (the CPU oracle on a bounded sample,
+rank 0, N=1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: cells, genes, density, conditions, replicates, bootstraps   (BASELINE.json configs[1], [2])
+    "C2": dict(cells=100_000, genes=20_000, density=0.05, n_cond=2, n_rep=4, num_boot=1_000),
+    "C3": dict(cells=1_000_000, genes=20_000, density=0.03, n_cond=2, n_rep=10, num_boot=10_000),
+    "tiny": dict(cells=6_000, genes=400, density=0.08, n_cond=2, n_rep=2, num_boot=200),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def synth_device_csr(cfg, seed, torch):
+    """Gamma-Poisson counts generated ON THE GPU (SURVEY.md section 8d shape); returns engine.DeviceCSR."""
+    from scrna_parameter_estimation_amd import engine
+    from scrna_parameter_estimation_amd.synth import _expected_density
+
+    N, G, dens = cfg["cells"], cfg["genes"], cfg["density"]
+    rng = np.random.default_rng(seed)
+    mu = rng.lognormal(-2.2, 1.2, size=G)
+    depth = rng.lognormal(0.0, 0.35, size=N)
+    nodes = np.quantile(depth, (np.arange(64) + 0.5) / 64)
+    w = np.full(64, 1.0 / 64)
+    lo, hi = 1e-4, 1e4
+    for _ in range(60):
+        mid = np.sqrt(lo * hi)
+        if _expected_density(mu, mid, nodes, w) < dens:
+            lo = mid
+        else:
+            hi = mid
+    mu = mu * np.sqrt(lo * hi)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    d_mu = torch.from_numpy(mu.astype(np.float32)).cuda()
+    d_depth = torch.from_numpy(depth.astype(np.float32)).cuda()
+    idx_parts, val_parts, cnt_parts = [], [], []
+    rows = 8192
+    for r0 in range(0, N, rows):
+        r1 = min(N, r0 + rows)
+        u = torch.rand((2, r1 - r0, G), generator=gen, device="cuda")
+        gam = -0.5 * torch.log(u[0] * u[1] + 1e-38)            # Gamma(2, scale 0.5)
+        lam = d_depth[r0:r1, None] * d_mu[None, :] * gam
+        x = torch.poisson(lam, generator=gen)
+        x = torch.clamp(x, max=500000.0)
+        nz = x != 0
+        cnt_parts.append(nz.sum(dim=1))
+        cols = nz.nonzero()[:, 1].to(torch.int32)
+        idx_parts.append(cols)
+        val_parts.append(x[nz])
+        del u, gam, lam, x, nz
+    counts = torch.cat(cnt_parts)
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+    indptr[1:] = torch.cumsum(counts, 0)
+    return engine.DeviceCSR.from_device(indptr, torch.cat(idx_parts), torch.cat(val_parts).to(torch.float32), (N, G))
+
+
+def sample_columns(csr, genes, torch):
+    """Dense host columns [N][len(genes)] of a device CSR (for the CPU baseline sample)."""
+    genes_t = torch.as_tensor(np.asarray(genes), dtype=torch.int32, device="cuda")
+    hit = torch.isin(csr.indices, genes_t)
+    pos = hit.nonzero()[:, 0]
+    rows = torch.searchsorted(csr.indptr, pos, right=True) - 1
+    cols = csr.indices[pos].long()
+    lut = torch.full((csr.shape[1],), -1, dtype=torch.int64, device="cuda")
+    lut[genes_t.long()] = torch.arange(len(genes), device="cuda")
+    out = np.zeros((csr.shape[0], len(genes)))
+    out[rows.cpu().numpy(), lut[cols].cpu().numpy()] = csr.data[pos].double().cpu().numpy()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=os.environ.get("MM_BENCH_CONFIG", "C3"), choices=list(CONFIGS))
+    ap.add_argument("--num-cpus", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        from scrna_parameter_estimation_amd.dist import Comm
+
+        comm = Comm(device="cuda")
+
+    from scrna_parameter_estimation_amd import AnnDataLite, engine, memento
+    from scrna_parameter_estimation_amd import _lib
+    import scipy.sparse as sp
+
+    _lib.load(require_gpu=True)
+    N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
+    n_groups = cfg["n_cond"] * cfg["n_rep"]
+
+    # ---- untimed preparation: data in HBM, size factors, groups + count blocks -------------------
+    t0 = time.time()
+    csr = synth_device_csr(cfg, 20250117 + 1000 * rank, torch)      # every rank: its own gene shard (same cells)
+    rng = np.random.default_rng(20250117)                            # identical cell metadata on all ranks
+    grp = rng.integers(0, n_groups, size=N)
+    obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
+    var = pd.DataFrame(index=[f"r{rank}g{i}" for i in range(G)])
+    Xstub = sp.csr_matrix((N, G), dtype=np.float32)                   # shape only: the counts live in HBM
+    adata = AnnDataLite(Xstub, obs, var)
+    memento.setup_memento(adata, q_column="q", device_csr=csr, comm=comm)
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == cfg["n_cond"] - 1).astype(float)}, index=gdf.index)
+    torch.cuda.synchronize()
+    prep_s = time.time() - t0
+    state = adata.uns["memento"]["_hip"]
+    full_idx = state.gene_idx.copy()
+
+    def step(seed):
+        # compute_1d_moments filters genes in place; restore the full gene set so every step does the same work
+        state.gene_idx = full_idx.copy()
+        state.var_names = None
+        for k in ("size_factor", "approx_size_factor", "all_approx_size_factor"):
+            adata.uns["memento"].pop(k, None)
+        for g in adata.uns["memento"]["groups"]:
+            adata.uns["memento"]["group_cells"][g].shape = (adata.uns["memento"]["group_cells"][g].shape[0], G)
+        np.random.seed(seed)
+        memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+        memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=B, num_cpus=args.num_cpus, verbose=0,
+                              resampling="bootstrap", approx=False)
+        return len(adata.uns["memento"]["1d_ht"]["mean_asl"])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(100 + w)
+    barrier()
+    t0 = time.time()
+    n_tests = 0
+    for k in range(args.steps):
+        n_tests += step(1000 + k)
+    barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        nt = torch.tensor([float(n_tests)], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(nt, op=torch.distributed.ReduceOp.SUM)
+        elapsed, n_tests = float(tt.item()), float(nt.item())
+
+    # ---- roofline of the dominant HBM kernel (K1 moments) and bootstrap draw rate, rank 0 --------
+    roof = boot = cpu = None
+    if rank == 0:
+        blocks = state.blocks
+        stream = engine._stream()
+        d_inv = engine.dev((1.0 / adata.obs["memento_size_factor"].values)[blocks.cell_order])
+        import ctypes
+
+        timer = ctypes.c_void_p()
+        _lib.call("mm_timer_create", ctypes.byref(timer))
+        for _ in range(3):
+            blocks.launch_moments(d_inv)
+        reps = 20
+        _lib.call("mm_timer_begin", timer, stream)
+        for _ in range(reps):
+            blocks.launch_moments(d_inv)
+        _lib.call("mm_timer_end", timer, stream)
+        ms = ctypes.c_float()
+        _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(ms))
+        k1_ms = ms.value / reps
+        nbytes = blocks.moments_bytes()
+        achieved = nbytes / (k1_ms * 1e-3) / 1e9
+        roof = {"kernel": "k_moments1d_sell", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(nbytes),
+                "ms_per_launch": round(k1_ms, 4), "nnz": int(blocks.nnz_sel)}
+        bs = state.last_bootstrap
+        # time one replay launch by itself (HIP events on the launch stream)
+        skip = ~((bs.K >= 2))
+        r = np.random.default_rng(0).random((2, bs.n_pairs))
+        _lib.call("mm_timer_begin", timer, stream)
+        bs.run(skip, r[0], r[1], adata.uns["memento"]["mv_regressor"]["all"])
+        _lib.call("mm_timer_end", timer, stream)
+        _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(ms))
+        draws = bs.draws_per_replicate * B
+        boot = {"kernel": "k_boot1d_replay(+order,fill)", "binomial_draws": int(draws), "ms": round(ms.value, 2),
+                "draws_per_s": round(draws / (ms.value * 1e-3), 1), "pairs": int((~skip).sum()), "waves": int(bs.n_tiles), "K_max": int(bs.K.max()), "K_mean": round(float(bs.K[~skip].mean()), 1),
+                "rng": "numpy-PCG64-replay"}
+        _lib.call("mm_timer_destroy", timer)
+
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch)
+
+    if rank == 0:
+        value = n_tests / elapsed
+        line = {
+            "metric": "gene-tests/sec (1D moments + bootstrap hypothesis test)", "value": round(value, 2), "unit": "gene-tests/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {N} cells x {G} genes/GPU, {cfg['density']:.0%} nnz, {n_groups} groups, "
+                                   f"{B} bootstraps, 1D moments + ht (resampling=bootstrap, approx=False)",
+                       "rng": "numpy PCG64 multinomial replay; device refill of invalid replicates", "parallelism": f"genes x{world}",
+                       "host_tail_fit_procs": args.num_cpus, "prep_s": round(prep_s, 2)},
+            "roofline": roof, "bootstrap": boot, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch):
+    """The CPU oracle (numpy restatement pinned to the reference) on a bounded sample of genes, 1 core."""
+    from oracle import memento_oracle as orc
+
+    m = adata.uns["memento"]
+    groups = m["groups"]
+    ng = len(groups)
+    kept = state.gene_idx
+    n_try = 64
+    pick = kept[:: max(1, len(kept) // n_try)][:n_try]
+    cols = sample_columns(csr, pick, torch)
+    gid = state.group_id
+    sel = [np.flatnonzero(gid == k) for k in range(ng)]
+    sf = adata.obs["memento_size_factor"].values
+    asf = [m["all_approx_size_factor"][s] for s in sel]
+    gq = np.array([m["group_q"][g] for g in groups])
+    Nc = np.array([len(s) for s in sel], dtype=float)
+    slot = {g: i for i, g in enumerate(kept)}
+    tm = np.stack([m["1d_moments"][g][0] for g in groups])
+    trv = np.stack([m["1d_moments"][g][2] for g in groups])
+    fit = m["mv_regressor"]["all"]
+    np.random.seed(0)
+    t0 = time.time()
+    done = 0
+    for j, g in enumerate(pick):
+        col = cols[:, j]
+        # moments part of the step for this gene (estimator.py:177-183)
+        for k in range(ng):
+            x = col[sel[k]]
+            w = 1.0 / sf[sel[k]]
+            _ = ((x * w).sum(), (x * x * w * w).sum(), (x * w * w).sum())
+        orc.ht_1d_gene(tm[:, slot[g]], trv[:, slot[g]], [col[s] for s in sel], asf, cov.values, trt.values, Nc,
+                       cfg["num_boot"], fit, gq, resampling="bootstrap", approx=False)
+        done += 1
+        if time.time() - t0 > args.cpu_baseline_seconds:
+            break
+    dt = time.time() - t0
+    return {"value": round(done * trt.shape[1] / dt, 4), "unit": "gene-tests/s", "cores": 1, "kind": "port",
+            "sample": f"{done} genes x {ng} groups x {cfg['num_boot']} bootstraps of the same matrix, oracle/memento_oracle.py, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

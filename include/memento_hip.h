@@ -114,28 +114,32 @@ int mm_bins_count(uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xc
 
 /* ---- K5b+K6 prep: order the bins like np.unique(code) and lay them out for the bootstrap ---------
  * code = count*r1 + r0*approx_sf[sf_bin] in IEEE fp64 (memento/bootstrap.py:62-67); ascending.
- * Pairs are assigned to lanes of 64-wide tiles (d_pair_slot[p] = tile*64+lane or -1 to skip);
- * tile t owns bin rows [tile_ptr[t], tile_ptr[t+1]) of 64 lanes each.  Per bin the kernel writes
- *   pix = mult/N_g, v = count, a = 1/sf, b = 1/sf^2, c1 = (1-q)*count, v2 = count^2   (fp64 each)
- * at [ (tile_ptr[t]+k)*64 + lane ].  d_status[0] is set if two bins of a pair collide in code. */
+ * Pairs are assigned to lanes of 64-wide tiles (d_pair_slot[p] = tile*64+lane or -1 to skip; a tile may
+ * leave lanes empty); tile t owns bin rows [tile_ptr[t], tile_ptr[t+1]) of 64 lanes each.  Per bin k the
+ * kernel writes, at [(tile_ptr[t]+k)*64 + lane]:
+ *   pk = pix[k]/remaining_p  with pix = mult/N_g and remaining_p as numpy's random_multinomial updates it
+ *        (replicate-independent), lq = log(1-p) as the inversion sampler needs it,
+ *   v = count, a = 1/sf, b = 1/sf^2                                              (fp64 each).
+ * d_status[0] |= 8 if two bins of a pair collide in code (np.unique would merge them). */
 int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap, const int32_t *d_K,
                   const int64_t *d_pair_list, int64_t n_list /* pairs handled by this launch */,
                   int32_t big /* 0: K <= 1024 (one wave per pair); 1: K <= 8192 (512 threads per pair) */, int32_t n_groups,
                   int32_t n_sf_bins, const double *d_sf_table /* [n_sf_bins] approx size factor of each bin */,
                   const double *d_r1, const double *d_r0 /* per pair */, const int64_t *d_pair_slot, const int64_t *d_tile_ptr,
-                  const double *d_grp_ncells /* [n_groups] */, const double *d_grp_q /* [n_groups] */, double *d_pix, double *d_v,
-                  double *d_a, double *d_b, double *d_c1, double *d_v2, int32_t *d_status, void *stream);
+                  const double *d_grp_ncells /* [n_groups] */, double *d_pk, double *d_lq, double *d_v, double *d_a, double *d_b,
+                  int32_t *d_status, void *stream);
 
 /* ---- K6+K7: replay bootstrap -- numpy Generator(PCG64).multinomial draw-for-draw + replicate moments
  * replaces bootstrap._bootstrap_1d  memento/bootstrap.py:97-110 and the tuple branch of
  * estimator._hyper_1d_relative  memento/estimator.py:171-174, :182-183.
  * One lane per (gene, group) pair, one sequential PCG64 stream per lane (the reference re-seeds PCG64(5)
  * for every pair, bootstrap.py:102).  pcg_state = {state_hi, state_lo, inc_hi, inc_lo}.
- * Writes mean_b / var_b to d_out_mean[row*ld + 1 + b], row = d_slot_row[slot]; K<=1 pairs get NaN rows.
+ * d_slot_nobs = N_g, d_slot_omq = 1 - q_g of the slot's group.
+ * Writes mean_b / var_b to d_out_mean[row*ld + 1 + b], row = d_slot_row[slot]; K == 1 pairs get NaN rows.
  * d_w_dump (optional, NULL in production) receives the int32 weights [slot][k][b] with stride kmax_dump. */
-int mm_boot1d_replay(const double *d_pix, const double *d_v, const double *d_a, const double *d_b, const double *d_c1,
-                     const double *d_v2, const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K,
-                     const double *d_slot_nobs, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
+int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
+                     const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
+                     const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
                      int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream);
 
 /* ---- K8: residual variance, invalid-replicate fill, log  ---------------------------------------

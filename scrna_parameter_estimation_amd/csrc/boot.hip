@@ -14,12 +14,12 @@
 #include "mm_common.h"
 #include "npy_rng.h"
 
-__global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict__ pix, const double *__restrict__ v,
-                                                       const double *__restrict__ a, const double *__restrict__ b,
-                                                       const double *__restrict__ c1, const double *__restrict__ v2,
+__global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
+                                                       const double *__restrict__ v, const double *__restrict__ a,
+                                                       const double *__restrict__ b,
                                                        const int64_t *__restrict__ tile_ptr, int64_t n_tiles,
                                                        const int32_t *__restrict__ slot_K, const double *__restrict__ slot_nobs,
-                                                       const int64_t *__restrict__ slot_row, uint64_t st0, uint64_t st1,
+                                                       const double *__restrict__ slot_omq, const int64_t *__restrict__ slot_row, uint64_t st0, uint64_t st1,
                                                        uint64_t st2, uint64_t st3, int32_t num_boot, int64_t ld,
                                                        double *__restrict__ out_mean, double *__restrict__ out_var,
                                                        int32_t *__restrict__ w_dump, int32_t kmax_dump) {
@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict_
   int64_t row0 = tile_ptr[tile];
   int kmax = (int)(tile_ptr[tile + 1] - row0);
   double nobs = slot_nobs[slot];
-  int64_t n = (int64_t)nobs;
+  double omq = slot_omq[slot];  // 1 - q of the pair's group
+  int32_t n = (int32_t)nobs;  // N_g < 2^31 (checked by the host)
   double *om = out_mean + row * ld + 1;
   double *ov = out_var + row * ld + 1;
   if (K == 1) {  // bootstrap.py:97-98: a single bin -> all-NaN replicates
@@ -45,21 +46,19 @@ __global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict_
   npyrng::Pcg64 g{st0, st1, st2, st3};
   const bool run = K >= 2;
   for (int r = 0; r < num_boot; r++) {
-    double M1 = 0.0, M2 = 0.0, rem = 1.0;
-    int64_t dn = n;
+    double M1 = 0.0, M2 = 0.0;
+    int32_t dn = n;
     bool live = true;
     for (int k = 0; k < kmax; k++) {
       if (run && k < K) {
         int64_t o = (row0 + k) * 64 + lane;
-        int64_t w;
+        int32_t w;
         if (k < K - 1) {
           w = 0;
           if (live) {
-            double pk = pix[o];
-            w = npyrng::binomial(g, pk / rem, dn);
+            w = npyrng::binomial_pre<int32_t>(g, pk_[o], lq_[o], dn);
             dn -= w;
             if (dn <= 0) live = false;
-            else rem -= pk;
           }
         } else {
           w = dn > 0 ? dn : 0;
@@ -67,9 +66,9 @@ __global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict_
         if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = (int32_t)w;
         if (w != 0) {
           double wd = (double)w;
-          double bb = b[o];
-          M1 += (v[o] * wd) * a[o];
-          M2 += (v2[o] * wd) * bb - (c1[o] * wd) * bb;
+          double bb = b[o], vv = v[o];
+          M1 += (vv * wd) * a[o];
+          M2 += ((vv * vv) * wd) * bb - ((omq * vv) * wd) * bb;
         }
       }
     }
@@ -164,16 +163,16 @@ __global__ __launch_bounds__(256) void k_boot_fill_log(double *__restrict__ mean
 
 extern "C" {
 
-int mm_boot1d_replay(const double *d_pix, const double *d_v, const double *d_a, const double *d_b, const double *d_c1,
-                     const double *d_v2, const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K,
-                     const double *d_slot_nobs, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
+int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
+                     const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
+                     const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
                      int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream) {
-  MM_ARG(d_pix && d_v && d_a && d_b && d_c1 && d_v2 && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_row && pcg_state);
+  MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   MM_ARG(d_out_mean && d_out_var && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
   int64_t blocks = (n_tiles + 3) / 4;
-  hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pix, d_v, d_a, d_b, d_c1, d_v2,
-                     d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2], pcg_state[3],
+  hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
+                     d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2], pcg_state[3],
                      num_boot, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump);
   MM_LAUNCH_CHECK();
   return MM_OK;

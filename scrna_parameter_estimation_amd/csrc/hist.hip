@@ -6,6 +6,7 @@
 // The bins as a SET are deterministic integers (bit-exact); their ORDER is ascending `code`, computed
 // here in IEEE fp64 with contraction off so it equals numpy's sort order.  Compile with -ffp-contract=off.
 #include "mm_common.h"
+#include "npy_rng.h"
 #include <math.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(NT) void k_bins_order(const uint32_t *__restrict__ 
                                                    int32_t n_sf_bins, const double *__restrict__ sf_table,
                                                    const double *__restrict__ r1a, const double *__restrict__ r0a,
                                                    const int64_t *__restrict__ pair_slot, const int64_t *__restrict__ tile_ptr,
-                                                   const double *__restrict__ grp_ncells, const double *__restrict__ grp_q,
-                                                   double *__restrict__ o_pix, double *__restrict__ o_v, double *__restrict__ o_a,
-                                                   double *__restrict__ o_b, double *__restrict__ o_c1, double *__restrict__ o_v2,
+                                                   const double *__restrict__ grp_ncells,
+                                                   double *__restrict__ o_pk, double *__restrict__ o_lq, double *__restrict__ o_v,
+                                                   double *__restrict__ o_a, double *__restrict__ o_b,
                                                    int32_t *__restrict__ status) {
   extern __shared__ double smem_d[];
   double *code = smem_d;                       // [CAP]
@@ -189,20 +190,30 @@ __global__ __launch_bounds__(NT) void k_bins_order(const uint32_t *__restrict__ 
   int64_t tile = slot >> 6, ln = slot & 63;
   int64_t row0 = tile_ptr[tile];
   double N = grp_ncells[grp];
-  double omq = 1.0 - grp_q[grp];
   bool tie = false;
+  for (int k = tid; k + 1 < K; k += NT)
+    if (code[k] == code[k + 1]) tie = true;
+  __syncthreads();
+  // numpy: remaining_p starts at 1.0 and loses pix[j] after every drawn bin (sequential rounding), so the
+  // success probability of bin k, pix[k]/remaining_p, is replicate-independent: compute it once here.
+  if (tid == 0) {
+    double rem = 1.0;
+    for (int k = 0; k < K; k++) {
+      code[k] = rem;  // the sort keys are no longer needed
+      rem -= (double)mult[k] / N;
+    }
+  }
+  __syncthreads();
   for (int k = tid; k < K; k += NT) {
-    if (k + 1 < K && code[k] == code[k + 1]) tie = true;
     uint32_t bin = pay[k] >> 19, x = pay[k] & ((1u << 19) - 1u);
     double sf = sf_table[bin];
-    double v = (double)x;
+    double pk = ((double)mult[k] / N) / code[k];
     int64_t o = (row0 + k) * 64 + ln;
-    o_pix[o] = (double)mult[k] / N;
-    o_v[o] = v;
+    o_pk[o] = pk;
+    o_lq[o] = npyrng::binomial_lq(pk);
+    o_v[o] = (double)x;
     o_a[o] = 1.0 / sf;
     o_b[o] = 1.0 / (sf * sf);
-    o_c1[o] = omq * v;
-    o_v2[o] = v * v;
   }
   if (tie) atomicOr(status, 8);  // np.unique would merge these two bins; caller must handle (never seen in practice)
 }
@@ -241,24 +252,24 @@ int mm_bins_count(uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xc
 int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap, const int32_t *d_K,
                   const int64_t *d_pair_list, int64_t n_list, int32_t big, int32_t n_groups, int32_t n_sf_bins,
                   const double *d_sf_table, const double *d_r1, const double *d_r0, const int64_t *d_pair_slot,
-                  const int64_t *d_tile_ptr, const double *d_grp_ncells, const double *d_grp_q, double *d_pix, double *d_v,
-                  double *d_a, double *d_b, double *d_c1, double *d_v2, int32_t *d_status, void *stream) {
+                  const int64_t *d_tile_ptr, const double *d_grp_ncells, double *d_pk, double *d_lq, double *d_v,
+                  double *d_a, double *d_b, int32_t *d_status, void *stream) {
   MM_ARG(d_tab && d_tab_ptr && d_xcap && d_K && d_pair_list && d_sf_table && d_r1 && d_r0 && d_pair_slot && d_tile_ptr);
-  MM_ARG(d_grp_ncells && d_grp_q && d_pix && d_v && d_a && d_b && d_c1 && d_v2 && d_status && n_list >= 0 && n_sf_bins <= 256);
+  MM_ARG(d_grp_ncells && d_pk && d_lq && d_v && d_a && d_b && d_status && n_list >= 0 && n_sf_bins <= 256);
   if (n_list == 0) return MM_OK;
   if (!big) {
     constexpr int CAP = 1024, NT = 64;
     size_t shm = (size_t)CAP * 16;
     hipLaunchKernelGGL((k_bins_order<CAP, NT>), dim3((unsigned)n_list), dim3(NT), shm, (hipStream_t)stream, d_tab, d_tab_ptr, d_xcap,
                        d_K, d_pair_list, n_list, n_groups, n_sf_bins, d_sf_table, d_r1, d_r0, d_pair_slot, d_tile_ptr, d_grp_ncells,
-                       d_grp_q, d_pix, d_v, d_a, d_b, d_c1, d_v2, d_status);
+                       d_pk, d_lq, d_v, d_a, d_b, d_status);
   } else {
     constexpr int CAP = 8192, NT = 512;
     size_t shm = (size_t)CAP * 16;
     MM_HIP(hipFuncSetAttribute((const void *)k_bins_order<CAP, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL((k_bins_order<CAP, NT>), dim3((unsigned)n_list), dim3(NT), shm, (hipStream_t)stream, d_tab, d_tab_ptr, d_xcap,
                        d_K, d_pair_list, n_list, n_groups, n_sf_bins, d_sf_table, d_r1, d_r0, d_pair_slot, d_tile_ptr, d_grp_ncells,
-                       d_grp_q, d_pix, d_v, d_a, d_b, d_c1, d_v2, d_status);
+                       d_pk, d_lq, d_v, d_a, d_b, d_status);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;

@@ -61,13 +61,14 @@ NPY_HD double pcg64_next_double(Pcg64 &g) {
 }
 
 // ---- binomial: inversion for n*p <= 30 -------------------------------------------------------
-NPY_HD int64_t binomial_inversion(Pcg64 &g, int64_t n, double p) {
+template <typename Int>
+NPY_HD Int binomial_inversion(Pcg64 &g, Int n, double p) {
   double q = 1.0 - p;
   double qn = exp((double)n * log(q));
   double np_ = (double)n * p;
   double bd = np_ + 10.0 * sqrt(np_ * q + 1);
-  int64_t bound = (int64_t)((double)n < bd ? (double)n : bd);
-  int64_t X = 0;
+  Int bound = (Int)((double)n < bd ? (double)n : bd);
+  Int X = 0;
   double px = qn;
   double U = pcg64_next_double(g);
   while (U > px) {
@@ -78,7 +79,7 @@ NPY_HD int64_t binomial_inversion(Pcg64 &g, int64_t n, double p) {
       U = pcg64_next_double(g);
     } else {
       U -= px;
-      px = ((double)(n - X + 1) * p * px) / ((double)X * q);
+      px = (((double)(n - X) + 1.0) * p * px) / ((double)X * q);
     }
   }
   return X;
@@ -89,11 +90,12 @@ NPY_HD double btpe_stirling(double x, double x2) {
 }
 
 // ---- binomial: BTPE for n*p > 30, p <= 0.5 ----------------------------------------------------
-NPY_HD int64_t binomial_btpe(Pcg64 &g, int64_t n, double p) {
+template <typename Int>
+NPY_HD Int binomial_btpe(Pcg64 &g, Int n, double p) {
   double r = p < 1.0 - p ? p : 1.0 - p;
   double q = 1.0 - r;
   double fm = (double)n * r + r;
-  int64_t m = (int64_t)floor(fm);
+  Int m = (Int)floor(fm);
   double p1 = floor(2.195 * sqrt((double)n * r * q) - 4.6 * q) + 0.5;
   double xm = (double)m + 0.5;
   double xl = xm - p1;
@@ -107,38 +109,38 @@ NPY_HD int64_t binomial_btpe(Pcg64 &g, int64_t n, double p) {
   double p3 = p2 + c / laml;
   double p4 = p3 + c / lamr;
   double nrq = (double)n * r * q;
-  int64_t y;
+  Int y;
   for (;;) {
     double u = pcg64_next_double(g) * p4;
     double v = pcg64_next_double(g);
     if (u <= p1) {
-      y = (int64_t)floor(xm - p1 * v + u);
+      y = (Int)floor(xm - p1 * v + u);
       break;  // accept (triangular region)
     }
     if (u <= p2) {  // parallelogram
       double x = xl + (u - p1) / c;
       v = v * c + 1.0 - fabs((double)m - x + 0.5) / p1;
       if (v > 1.0) continue;
-      y = (int64_t)floor(x);
+      y = (Int)floor(x);
     } else if (u <= p3) {  // left exponential tail
-      y = (int64_t)floor(xl + log(v) / laml);
+      y = (Int)floor(xl + log(v) / laml);
       if (y < 0 || v == 0.0) continue;
       v = v * (u - p2) * laml;
     } else {  // right exponential tail
-      y = (int64_t)floor(xr - log(v) / lamr);
+      y = (Int)floor(xr - log(v) / lamr);
       if (y > n || v == 0.0) continue;
       v = v * (u - p3) * lamr;
     }
-    int64_t k = y > m ? y - m : m - y;
+    Int k = y > m ? y - m : m - y;
     if (!((k > 20) && ((double)k < nrq / 2.0 - 1))) {
       // explicit evaluation of f(y)/f(m)
       double s = r / q;
-      double aa = s * (double)(n + 1);
+      double aa = s * ((double)n + 1.0);
       double F = 1.0;
       if (m < y) {
-        for (int64_t i = m + 1; i <= y; i++) F *= (aa / (double)i - s);
+        for (Int i = m + 1; i <= y; i++) F *= (aa / (double)i - s);
       } else if (m > y) {
-        for (int64_t i = y + 1; i <= m; i++) F /= (aa / (double)i - s);
+        for (Int i = y + 1; i <= m; i++) F /= (aa / (double)i - s);
       }
       if (v > F) continue;
       break;
@@ -146,14 +148,14 @@ NPY_HD int64_t binomial_btpe(Pcg64 &g, int64_t n, double p) {
     // squeeze, then Stirling-corrected comparison
     double kd = (double)k;
     double rho = (kd / nrq) * ((kd * (kd / 3.0 + 0.625) + 0.16666666666666666) / nrq + 0.5);
-    double t = (double)(-k * k) / (2 * nrq);
+    double t = -(kd * kd) / (2 * nrq);  // == (double)(-k*k): the exact integer k^2 rounds the same way
     double A = log(v);
     if (A < (t - rho)) break;
     if (A > (t + rho)) continue;
-    double x1 = (double)(y + 1);
-    double f1 = (double)(m + 1);
-    double z = (double)(n + 1 - m);
-    double w = (double)(n - y + 1);
+    double x1 = (double)y + 1.0;
+    double f1 = (double)m + 1.0;
+    double z = (double)(n - m) + 1.0;  // exact: |n - m| < 2^53
+    double w = (double)(n - y) + 1.0;
     double x2 = x1 * x1, f2 = f1 * f1, z2 = z * z, w2 = w * w;
     double bound = xm * log(f1 / x1) + ((double)(n - m) + 0.5) * log(z / w) +
                    (double)(y - m) * log(w * r / (x1 * q)) + btpe_stirling(f1, f2) +
@@ -164,15 +166,68 @@ NPY_HD int64_t binomial_btpe(Pcg64 &g, int64_t n, double p) {
   return y;
 }
 
-NPY_HD int64_t binomial(Pcg64 &g, double p, int64_t n) {
+// ---- hoisted form used by the bootstrap kernel -------------------------------------------------
+// In numpy's multinomial chain the success probability of bin k, pix[k]/remaining_p, does not depend on
+// the draws (remaining_p only shrinks by the pix of earlier bins until the chain stops), so everything
+// that depends on p alone -- the p > 0.5 flip, q = 1 - p and log(q) -- is computed ONCE per bin
+// instead of once per replicate.  The arithmetic and its rounding are unchanged.
+// log(1 - p) for the p that random_binomial hands to the inversion sampler (after the p > 0.5 flip)
+NPY_HD double binomial_lq(double pk) {
+  double p = pk <= 0.5 ? pk : 1.0 - pk;
+  return log(1.0 - p);
+}
+
+template <typename Int>
+NPY_HD Int binomial_inversion_pre(Pcg64 &g, Int n, double p, double lq) {
+  double q = 1.0 - p;
+  double qn = exp((double)n * lq);
+  Int bound = -1;  // computed lazily: np + 10*sqrt(np*q+1) >= 10, so X <= min(n, 9) can never exceed it
+  Int X = 0;
+  double px = qn;
+  double U = pcg64_next_double(g);
+  while (U > px) {
+    X++;
+    bool over = false;
+    if (X > 9 || X > n) {
+      if (bound < 0) {
+        double np_ = (double)n * p;
+        double bd = np_ + 10.0 * sqrt(np_ * q + 1);
+        bound = (Int)((double)n < bd ? (double)n : bd);
+      }
+      over = X > bound;
+    }
+    if (over) {
+      X = 0;
+      px = qn;
+      U = pcg64_next_double(g);
+    } else {
+      U -= px;
+      px = (((double)(n - X) + 1.0) * p * px) / ((double)X * q);
+    }
+  }
+  return X;
+}
+
+// binomial(pk, n) with lq = binomial_lq(pk) precomputed; identical draws to binomial(g, pk, n).
+template <typename Int>
+NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
+  if (n == 0 || pk == 0.0) return 0;
+  bool flip = !(pk <= 0.5);
+  double p = flip ? 1.0 - pk : pk;
+  Int X = (p * (double)n <= 30.0) ? binomial_inversion_pre<Int>(g, n, p, lq) : binomial_btpe<Int>(g, n, p);
+  return flip ? n - X : X;
+}
+
+template <typename Int>
+NPY_HD Int binomial(Pcg64 &g, double p, Int n) {
   if (n == 0 || p == 0.0) return 0;
   if (p <= 0.5) {
-    if (p * (double)n <= 30.0) return binomial_inversion(g, n, p);
-    return binomial_btpe(g, n, p);
+    if (p * (double)n <= 30.0) return binomial_inversion<Int>(g, n, p);
+    return binomial_btpe<Int>(g, n, p);
   }
   double q = 1.0 - p;
-  if (q * (double)n <= 30.0) return n - binomial_inversion(g, n, q);
-  return n - binomial_btpe(g, n, q);
+  if (q * (double)n <= 30.0) return n - binomial_inversion<Int>(g, n, q);
+  return n - binomial_btpe<Int>(g, n, q);
 }
 
 }  // namespace npyrng

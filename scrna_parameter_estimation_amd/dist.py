@@ -1,0 +1,52 @@
+"""Multi-GPU: one process per GPU, GENES sharded over ranks (every rank holds all cells x its genes).
+
+Genes are independent in every phase of the hot path after the size factors (SURVEY.md section 8e;
+/root/reference/memento/main.py:379-397), so the data path needs NO collective.  Two small exchanges
+remain, both outside the O(nnz) kernels:
+  * per-cell totals for the size factors  -> all-reduce(sum) of an N-vector  (estimator.py:65, :73)
+  * the pooled mean-variance fit          -> all-gather of per-gene moments   (main.py:232-245, :68-71)
+They run over torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+
+import numpy as np
+
+
+class Comm:
+    """Thin numpy-in / numpy-out wrapper around torch.distributed for the two exchanges above."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+
+    def allreduce_sum(self, a):
+        t = self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allgather_concat(self, a):
+        """Concatenate 1-D float arrays of different lengths from all ranks, in rank order."""
+        torch, dist = self.torch, self.dist
+        a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        n = torch.tensor([a.shape[0]], dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes + [1])
+        buf = torch.zeros(mx, dtype=torch.float64, device=self.device)
+        buf[: a.shape[0]] = torch.from_numpy(a).to(self.device)
+        out = [torch.zeros_like(buf) for _ in range(self.world)]
+        dist.all_gather(out, buf)
+        return np.concatenate([o[:s].cpu().numpy() for o, s in zip(out, sizes)])
+
+
+def shard_genes(n_genes, rank, world):
+    """Contiguous gene shard [lo, hi) of rank ``rank``."""
+    lo = (n_genes * rank) // world
+    hi = (n_genes * (rank + 1)) // world
+    return lo, hi

@@ -16,6 +16,10 @@ BLOCK_CELLS = 8192
 MAX_COUNT = (1 << 19) - 1
 ORDER_SMALL_CAP = 1024
 ORDER_BIG_CAP = 8192
+# lane-packing cost model of the replay kernel (instructions per bin step: C0 + C1 * active lanes)
+PACK_C0 = float(__import__('os').environ.get('MM_PACK_C0', 250))
+PACK_C1 = float(__import__('os').environ.get('MM_PACK_C1', 14))
+PACK_WAVES = int(__import__('os').environ.get('MM_PACK_WAVES', 1024))
 
 
 def _torch():
@@ -63,6 +67,17 @@ def host(t, dtype=None):
 
 class DeviceCSR:
     """The user's CSR on the device: indptr int64, indices int32, data float32 (integer-valued counts)."""
+
+    @classmethod
+    def from_device(cls, indptr, indices, data, shape):
+        """Wrap CSR arrays that already live in HBM (torch cuda tensors: int64 / int32 / float32)."""
+        torch = _torch()
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32 and data.dtype == torch.float32
+        self = cls.__new__(cls)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.nnz = int(indices.numel())
+        self.indptr, self.indices, self.data = indptr.contiguous(), indices.contiguous(), data.contiguous()
+        return self
 
     def __init__(self, X):
         import scipy.sparse as sp
@@ -270,7 +285,7 @@ class Bootstrap1D:
         self.ym[:, 0] = dev(np.asarray(true_mean_log, dtype=np.float64))
         self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
 
-    def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0):
+    def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0, target_waves=PACK_WAVES):
         """Order bins, replay the bootstrap and fill/log for every pair >= ``first_pair`` that is not skipped.
 
         ``skip``[pair] bool; ``r1``/``r0``[pair] the two uniforms of bootstrap.py:62,65.  Rows below
@@ -286,40 +301,71 @@ class Bootstrap1D:
             raise NotImplementedError(f"a (gene, group) pair has more than {ORDER_BIG_CAP} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         n_act = len(order)
-        n_tiles = (n_act + 63) // 64
+        # Lane packing.  A pair is one sequential stream, so a wave costs about  K_max(lanes) x c(L)  with
+        # c(L) = C0 + C1*L instructions per bin step (lanes diverge between the inversion and BTPE samplers).
+        # Wide waves are the most instruction-efficient, but the heaviest pair bounds the makespan; so give every
+        # wave the same cost budget: L(K) = largest lane count with K*c(L) <= budget, and pick the budget (bisection)
+        # that yields about ``target_waves`` waves (a few per SIMD on 256 CUs x 4 SIMDs).
+        Ks = self.K[order].astype(np.float64)
+        C0, C1 = PACK_C0, PACK_C1
+
+        def lanes_for(budget):
+            return np.clip(np.floor((budget / np.maximum(Ks, 1.0) - C0) / C1), 1, 64)
+
+        lo_b, hi_b = C0 + C1, float(Ks.max() if n_act else 1.0) * (C0 + 64 * C1) * 4.0
+        for _ in range(50):
+            mid = 0.5 * (lo_b + hi_b)
+            if (1.0 / lanes_for(mid)).sum() > target_waves:
+                lo_b = mid
+            else:
+                hi_b = mid
+        lanes = lanes_for(hi_b).astype(np.int64) if n_act else np.zeros(0, dtype=np.int64)
+        lanes = np.maximum.accumulate(lanes)     # non-decreasing along the K-descending order
+        slot_of = np.zeros(n_act, dtype=np.int64)
+        n_tiles, pos = 0, 0
+        while pos < n_act:                      # lanes[] is non-decreasing along the K-descending order
+            L = int(lanes[pos])
+            run_end = int(np.searchsorted(lanes, L, side="right"))
+            cnt = run_end - pos
+            idx = np.arange(cnt)
+            slot_of[pos:run_end] = (n_tiles + idx // L) * 64 + idx % L
+            n_tiles += -(-cnt // L)
+            pos = run_end
         self.n_tiles = n_tiles
         pair_slot = np.full(self.n_pairs, -1, dtype=np.int64)
-        pair_slot[order] = np.arange(n_act)
+        pair_slot[order] = slot_of
         slot_pair = np.full(n_tiles * 64, -1, dtype=np.int64)
-        slot_pair[:n_act] = order
+        slot_pair[slot_of] = order
         slot_K = np.zeros(n_tiles * 64, dtype=np.int32)
-        slot_K[:n_act] = self.K[order]
+        slot_K[slot_of] = self.K[order]
         tile_k = slot_K.reshape(n_tiles, 64).max(axis=1) if n_tiles else np.zeros(0, dtype=np.int32)
         tile_ptr = np.concatenate([[0], np.cumsum(tile_k.astype(np.int64))]).astype(np.int64)
         rows = int(tile_ptr[-1])
         self.draws_per_replicate = int(np.maximum(self.K[order] - 1, 0).sum())
-        ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(6)]
+        ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(5)]
         d_pair_slot, d_tile_ptr = dev(pair_slot), dev(tile_ptr)
         status = zeros((1,), torch.int32)
         d_r1, d_r0 = dev(np.asarray(r1, dtype=np.float64)), dev(np.asarray(r0, dtype=np.float64))
-        d_sf, d_nc, d_q = dev(self.sf_table), dev(self.blocks.grp_ncells.astype(np.float64)), dev(self.grp_q)
+        d_sf, d_nc = dev(self.sf_table), dev(self.blocks.grp_ncells.astype(np.float64))
         small = order[self.K[order] <= ORDER_SMALL_CAP]
         big = order[self.K[order] > ORDER_SMALL_CAP]
         for lst, is_big in ((small, 0), (big, 1)):
             if len(lst):
                 d_lst = dev(lst)
                 _lib.call("mm_bins_order", P(self.tab), P(self.d_tab_ptr), P(self.d_xcap), P(self.d_K), P(d_lst), len(lst),
-                          is_big, ng, self.n_bins, P(d_sf), P(d_r1), P(d_r0), P(d_pair_slot), P(d_tile_ptr), P(d_nc), P(d_q),
+                          is_big, ng, self.n_bins, P(d_sf), P(d_r1), P(d_r0), P(d_pair_slot), P(d_tile_ptr), P(d_nc),
                           *[P(o) for o in ops], P(status), s)
         nobs = np.zeros(n_tiles * 64, dtype=np.float64)
-        nobs[:n_act] = self.blocks.grp_ncells[order % ng]
+        nobs[slot_of] = self.blocks.grp_ncells[order % ng]
+        omq = np.zeros(n_tiles * 64, dtype=np.float64)
+        omq[slot_of] = 1.0 - self.grp_q[order % ng]
         kmax_dump = int(tile_k.max()) if (dump_weights and n_tiles) else 0
         self.w_dump = zeros((n_tiles * 64, kmax_dump, B), torch.int32) if dump_weights else None
         self.kmax_dump = kmax_dump
         self.slot_pair, self.slot_K, self.pair_slot, self.tile_ptr = slot_pair, slot_K, pair_slot, tile_ptr
-        d_slot_K, d_nobs, d_slot_pair = dev(slot_K), dev(nobs), dev(slot_pair)
+        d_slot_K, d_nobs, d_omq, d_slot_pair = dev(slot_K), dev(nobs), dev(omq), dev(slot_pair)
         if n_tiles:
-            _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_slot_pair),
+            _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       pcg64_state(pcg_seed), B, ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, s)
         st = int(status.item())
         if st & 2 or st & 4:

@@ -62,6 +62,21 @@ def _tail_job(args):
     return tail_fit_asl(*args)
 
 
+_POOL = {}
+
+
+def get_pool(num_cpus):
+    """Persistent spawn-context process pool for the tail fits (created once, reused across calls; workers
+    import only numpy/scipy -- never the GPU runtime)."""
+    pool = _POOL.get(num_cpus)
+    if pool is None:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+
+        pool = _POOL[num_cpus] = ProcessPoolExecutor(max_workers=num_cpus, mp_context=mp.get_context("spawn"))
+    return pool
+
+
 def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1):
     """Vector of ASLs for all tests.
 
@@ -84,11 +99,7 @@ def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1):
         rows = fetch_rows(need)
         jobs = [(rows[i], float(c[t])) for i, t in enumerate(need)]
         if num_cpus and num_cpus > 1 and len(jobs) > 1:
-            import multiprocessing as mp
-            from concurrent.futures import ProcessPoolExecutor
-
-            with ProcessPoolExecutor(max_workers=min(num_cpus, len(jobs)), mp_context=mp.get_context("spawn")) as ex:
-                res = list(ex.map(_tail_job, jobs, chunksize=max(1, len(jobs) // (4 * num_cpus))))
+            res = list(get_pool(num_cpus).map(_tail_job, jobs, chunksize=max(1, len(jobs) // (4 * num_cpus))))
         else:
             res = [tail_fit_asl(*j) for j in jobs]
         asl[need] = res

@@ -83,8 +83,12 @@ def _moments_from_sums(S, n_obs, q):
 
 
 def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_percent=0.1, shrinkage=0.5, num_bins=30,
-                  estimator_type='hyper_relative'):
-    """Compute size factors and the all-cell moments (reference: memento/main.py:26-91)."""
+                  estimator_type='hyper_relative', *, device_csr=None, comm=None):
+    """Compute size factors and the all-cell moments (reference: memento/main.py:26-91).
+
+    Extensions: ``device_csr`` -- an ``engine.DeviceCSR`` already resident in HBM (``adata.X`` is then only
+    used for its shape); ``comm`` -- a ``dist.Comm`` when the GENES are sharded over ranks (every rank holds
+    all cells x its gene shard): per-cell totals are all-reduced so every rank gets the global size factors."""
     if not inplace:
         adata = adata.copy()
     assert adata.obs[q_column].max() < 1
@@ -99,22 +103,35 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
     m['num_bins'] = num_bins
 
     st = m['_hip'] = _HipState()
-    st.csr = engine.DeviceCSR(adata.X)
+    st.csr = device_csr if device_csr is not None else engine.DeviceCSR(adata.X)
+    st.comm = comm
     N, G = adata.shape
+    assert tuple(st.csr.shape) == (N, G)
     st.gene_idx = np.arange(G)
     naive = st.csr.rowsum()                                                   # estimator.py:64-69
+    if comm is not None:
+        naive = comm.allreduce_sum(naive)
     blocks_all = engine.CountBlocks(st.csr, np.zeros(N, dtype=np.int32), 1)
     with np.errstate(divide="ignore"):
         S, sumx, _ = blocks_all.moments(1.0 / naive)
     all_m, all_v = _moments_from_sums(S[:, 0], N, m['all_q'])                 # main.py:62-66
     all_m = all_m.copy()
     all_m[(sumx[0].astype(np.float64) / N) < filter_mean_thresh] = 0          # main.py:67
-    all_rv = _res_var(all_m, all_v, _mv_fit(all_m, all_v))                    # main.py:68
-    rv_ulim = np.quantile(all_rv[np.isfinite(all_rv)], trim_percent)          # main.py:71
+    if comm is None:
+        all_rv = _res_var(all_m, all_v, _mv_fit(all_m, all_v))                # main.py:68
+        rv_ulim = np.quantile(all_rv[np.isfinite(all_rv)], trim_percent)      # main.py:71
+    else:                                   # the fit and the quantile are over ALL genes: gather the shards
+        gm, gv = comm.allgather_concat(all_m), comm.allgather_concat(all_v)
+        fit0 = _mv_fit(gm, gv)
+        grv = _res_var(gm, gv, fit0)
+        rv_ulim = np.quantile(grv[np.isfinite(grv)], trim_percent)
+        all_rv = _res_var(all_m, all_v, fit0)
     all_rv[~np.isfinite(all_rv)] = np.inf
     mask = all_rv < rv_ulim                                                   # main.py:73
     m['least_variable_genes'] = adata.var.index[mask].tolist()
     nrc = st.csr.rowsum(mask)                                                 # estimator.py:73
+    if comm is not None:
+        nrc = comm.allreduce_sum(nrc)
     nrc = nrc + np.quantile(nrc, shrinkage)                                   # estimator.py:74
     size_factor = nrc / nrc.mean()                                            # estimator.py:75-76
     adata.obs['memento_size_factor'] = size_factor
@@ -233,8 +250,12 @@ def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=Tru
         else:
             st.var_names = np.asarray(adata.var.index)[overall]
     m['gene_rv_filter'] = {g: gene_rv_filter[i] for i, g in enumerate(groups)}
-    fit = _mv_fit(np.concatenate([mean[i][gene_rv_filter[i]] for i in range(ng)]),
-                  np.concatenate([var[i][gene_rv_filter[i]] for i in range(ng)]))              # main.py:232-245
+    fm = np.concatenate([mean[i][gene_rv_filter[i]] for i in range(ng)])
+    fv = np.concatenate([var[i][gene_rv_filter[i]] for i in range(ng)])
+    comm = getattr(st, 'comm', None)
+    if comm is not None:                    # gene-sharded: the pooled fit sees every rank's genes
+        fm, fv = comm.allgather_concat(fm), comm.allgather_concat(fv)
+    fit = _mv_fit(fm, fv)                                                                      # main.py:232-245
     m['mv_regressor'] = {'all': fit}
     for g in groups:
         m['mv_regressor'][g] = fit

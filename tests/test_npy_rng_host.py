@@ -46,11 +46,11 @@ def test_binomial_matches_numpy(shim, n, p):
     np.testing.assert_array_equal(out, ref)
 
 
-def _multi(shim, seed, n, pv, B):
+def _multi(shim, seed, n, pv, B, fn="host_multinomial"):
     d = len(pv)
     out = np.zeros((B, d), dtype=np.int64)
     pv = np.ascontiguousarray(pv, dtype=np.float64)
-    shim.host_multinomial(pcg_state(seed), ctypes.c_int64(n), pv.ctypes.data_as(ctypes.c_void_p), d, B,
+    getattr(shim, fn)(pcg_state(seed), ctypes.c_int64(n), pv.ctypes.data_as(ctypes.c_void_p), d, B,
                           out.ctypes.data_as(ctypes.c_void_p))
     return out
 
@@ -69,16 +69,20 @@ def test_multinomial_random_shapes(shim):
         mult = np.concatenate([rng.integers(1, 5000, size=max(1, d // 4)), rng.integers(1, 40, size=d - max(1, d // 4))])
         rng.shuffle(mult)
         n = int(mult.sum()) if trial % 3 else int(rng.integers(1, 10 ** 6))
+        if trial % 7 == 0:
+            n = int(rng.integers(10 ** 8, 2 ** 30))   # large N_g: still inside the kernel's int32 range
         pv = mult / mult.sum()
         B = 50
-        got = _multi(shim, 5, n, pv, B)
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
-        np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial} d={d} n={n}")
+        for fn in ("host_multinomial", "host_multinomial_pre"):
+            got = _multi(shim, 5, n, pv, B, fn)
+            np.testing.assert_array_equal(got, ref, err_msg=f"{fn} trial {trial} d={d} n={n}")
 
 
 def test_multinomial_golden_weights(shim, internals_small):
     it = internals_small
     for k in range(int(it["n_picks"])):
         mult = it[f"p{k}_counts"]
-        got = _multi(shim, 5, int(it[f"p{k}_n_obs"]), mult / mult.sum(), int(it["num_boot"]))
-        np.testing.assert_array_equal(got.T, it[f"p{k}_weights"])
+        for fn in ("host_multinomial", "host_multinomial_pre"):
+            got = _multi(shim, 5, int(it[f"p{k}_n_obs"]), mult / mult.sum(), int(it["num_boot"]), fn)
+            np.testing.assert_array_equal(got.T, it[f"p{k}_weights"])
