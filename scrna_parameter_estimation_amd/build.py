@@ -21,6 +21,8 @@ SOURCES = [
     ("contract.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# experiment hook: extra -D flags for kernel tuning (e.g. MM_EXTRA_DEFS="-DK1_UNROLL=8 -DMM_ITEM_ROWS=32")
+COMMON += os.environ.get("MM_EXTRA_DEFS", "").split()
 
 
 def _hipcc():

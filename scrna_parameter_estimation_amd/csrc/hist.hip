@@ -20,23 +20,28 @@ __global__ __launch_bounds__(K5_THREADS) void k_hist1d_sell(const u32x4 *__restr
                                                             const int32_t *__restrict__ gene_pairbase, const int64_t *__restrict__ tab_ptr,
                                                             const int32_t *__restrict__ xcap, uint32_t *__restrict__ tab) {
   __shared__ uint8_t bin_lds[MM_BLOCK_CELLS];
+  __shared__ int32_t ip[1025];
   int b = blockIdx.x / split, part = blockIdx.x % split;
   int c0 = blk_cell0[b], nc = blk_cell0[b + 1] - c0;
   for (int i = threadIdx.x; i < MM_BLOCK_CELLS; i += K5_THREADS) bin_lds[i] = i < nc ? sf_bin[c0 + i] : 0;
+  for (int i = threadIdx.x; i <= n_slices; i += K5_THREADS) ip[i] = item_ptr[(int64_t)b * (n_slices + 1) + i];
   __syncthreads();
   int lane = mm_lane();
   int wave = part * (K5_THREADS / 64) + (threadIdx.x >> 6);
   int nwaves = split * (K5_THREADS / 64);
   const int32_t *sw = slice_w + (int64_t)b * n_slices;
   const int32_t *sp = slice_ptr + (int64_t)b * (n_slices + 1);
-  const int32_t *ip = item_ptr + (int64_t)b * (n_slices + 1);
   const int32_t *pm = perm + (int64_t)b * n_slices * 64;
   int n_items = ip[n_slices];
   int64_t base = blk_base[b];
   int grp = blk_group[b];
-  int t = 0;
   for (int item = wave; item < n_items; item += nwaves) {
-    while (ip[t + 1] <= item) t++;
+    int lo = 0, hi = n_slices;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (ip[mid] <= item) lo = mid; else hi = mid;
+    }
+    int t = lo;
     int gene = pm[t * 64 + lane];
     int pb = gene >= 0 ? gene_pairbase[gene] : -1;
     if (__ballot(pb >= 0) == 0ull) continue;  // nobody in this slice is tested

@@ -36,7 +36,9 @@ static inline int mm_fail(int code, const char *fmt, const char *a, const char *
 #define MM_SLICE 64
 #define MM_JVEC 4
 // a work item is at most this many dwordx4 rows of one slice (64 rows * 1 KiB = 64 KiB of entries)
+#ifndef MM_ITEM_ROWS
 #define MM_ITEM_ROWS 64
+#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

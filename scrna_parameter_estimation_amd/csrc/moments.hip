@@ -10,8 +10,19 @@
 // Algorithmic bytes per entry: 4 (the packed entry); fp64 accumulation.
 #include "mm_common.h"
 
-#define K1_THREADS 512
+#ifndef K1_THREADS
+#define K1_THREADS 1024
+#endif
+#ifndef K1_UNROLL
 #define K1_UNROLL 4
+#endif
+#define K1_MAX_SLICES 1024  // G <= 65536
+#ifndef K1_PIPE
+#define K1_PIPE 1
+#endif
+#ifndef K1_WGS
+#define K1_WGS 2048  // target workgroups per launch
+#endif
 
 __device__ __forceinline__ void k1_acc(uint32_t e, const double *__restrict__ w_lds, double &a1, double &a2, double &a3,
                                        uint32_t &sx, uint32_t &mx) {
@@ -35,23 +46,31 @@ __global__ __launch_bounds__(K1_THREADS) void k_moments1d_sell(const u32x4 *__re
                                                                double *__restrict__ S2, double *__restrict__ S3,
                                                                uint32_t *__restrict__ SX, uint32_t *__restrict__ MX) {
   __shared__ double w_lds[MM_BLOCK_CELLS];
+  __shared__ int32_t ip[K1_MAX_SLICES + 1], sp[K1_MAX_SLICES + 1], sw[K1_MAX_SLICES];
   int b = blockIdx.x / split, part = blockIdx.x % split;
   int c0 = blk_cell0[b], nc = blk_cell0[b + 1] - c0;
   for (int i = threadIdx.x; i < MM_BLOCK_CELLS; i += K1_THREADS) w_lds[i] = i < nc ? inv_sf[c0 + i] : 0.0;
+  // the block's slice tables go to LDS too: the item -> slice lookup must not be a chain of global loads
+  for (int i = threadIdx.x; i <= n_slices; i += K1_THREADS) {
+    ip[i] = item_ptr[(int64_t)b * (n_slices + 1) + i];
+    sp[i] = slice_ptr[(int64_t)b * (n_slices + 1) + i];
+    if (i < n_slices) sw[i] = slice_w[(int64_t)b * n_slices + i];
+  }
   __syncthreads();
   int lane = mm_lane();
   int wave = part * (K1_THREADS / 64) + (threadIdx.x >> 6);
   int nwaves = split * (K1_THREADS / 64);
-  const int32_t *sw = slice_w + (int64_t)b * n_slices;
-  const int32_t *sp = slice_ptr + (int64_t)b * (n_slices + 1);
-  const int32_t *ip = item_ptr + (int64_t)b * (n_slices + 1);
   int n_items = ip[n_slices];
   int64_t base = blk_base[b];
   int64_t ibase = blk_item_base[b];
   // items are numbered slice-major; walk slices, taking this wave's share of the item ids
-  int t = 0;
   for (int item = wave; item < n_items; item += nwaves) {
-    while (ip[t + 1] <= item) t++;  // wave-uniform; slices are visited in increasing order
+    int lo = 0, hi = n_slices;  // last slice t with ip[t] <= item (wave-uniform binary search in LDS)
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (ip[mid] <= item) lo = mid; else hi = mid;
+    }
+    int t = lo;
     int k = item - ip[t];
     int r0 = k * MM_ITEM_ROWS;
     int r1 = min(sw[t], r0 + MM_ITEM_ROWS);
@@ -59,6 +78,42 @@ __global__ __launch_bounds__(K1_THREADS) void k_moments1d_sell(const u32x4 *__re
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     uint32_t sx = 0, mx = 0;
     int nr = r1 - r0, r = 0;
+#if K1_PIPE
+    // two-stage software pipeline: the loads of batch i+1 are in flight while batch i is consumed
+    u32x4 ea[K1_UNROLL], eb[K1_UNROLL];
+    int nb = nr / K1_UNROLL;
+    if (nb > 0) {
+#pragma unroll
+      for (int u = 0; u < K1_UNROLL; u++) ea[u] = __builtin_nontemporal_load(p + (int64_t)u * 64);
+    }
+    for (int bi = 0; bi < nb; bi += 2) {
+      if (bi + 1 < nb) {
+#pragma unroll
+        for (int u = 0; u < K1_UNROLL; u++) eb[u] = __builtin_nontemporal_load(p + (int64_t)((bi + 1) * K1_UNROLL + u) * 64);
+      }
+#pragma unroll
+      for (int u = 0; u < K1_UNROLL; u++) {
+        k1_acc(ea[u].x, w_lds, a1, a2, a3, sx, mx);
+        k1_acc(ea[u].y, w_lds, a1, a2, a3, sx, mx);
+        k1_acc(ea[u].z, w_lds, a1, a2, a3, sx, mx);
+        k1_acc(ea[u].w, w_lds, a1, a2, a3, sx, mx);
+      }
+      if (bi + 1 < nb) {
+        if (bi + 2 < nb) {
+#pragma unroll
+          for (int u = 0; u < K1_UNROLL; u++) ea[u] = __builtin_nontemporal_load(p + (int64_t)((bi + 2) * K1_UNROLL + u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < K1_UNROLL; u++) {
+          k1_acc(eb[u].x, w_lds, a1, a2, a3, sx, mx);
+          k1_acc(eb[u].y, w_lds, a1, a2, a3, sx, mx);
+          k1_acc(eb[u].z, w_lds, a1, a2, a3, sx, mx);
+          k1_acc(eb[u].w, w_lds, a1, a2, a3, sx, mx);
+        }
+      }
+    }
+    r = nb * K1_UNROLL;
+#else
     for (; r + K1_UNROLL <= nr; r += K1_UNROLL) {
       u32x4 e[K1_UNROLL];
 #pragma unroll
@@ -71,6 +126,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_moments1d_sell(const u32x4 *__re
         k1_acc(e[u].w, w_lds, a1, a2, a3, sx, mx);
       }
     }
+#endif
     for (; r < nr; r++) {
       u32x4 e = __builtin_nontemporal_load(p + (int64_t)r * 64);
       k1_acc(e.x, w_lds, a1, a2, a3, sx, mx);
@@ -131,11 +187,11 @@ int mm_moments1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const in
                       const double *d_inv_sf, int32_t n_blocks, int32_t n_genes, double *d_S1, double *d_S2, double *d_S3,
                       uint32_t *d_SX, uint32_t *d_MX, void *stream) {
   MM_ARG(d_ent && d_blk_base && d_slice_w && d_slice_ptr && d_item_ptr && d_blk_item_base && d_blk_cell0 && d_inv_sf);
-  MM_ARG(d_S1 && d_S2 && d_S3 && d_SX && d_MX && n_blocks >= 0 && n_genes > 0);
+  MM_ARG(d_S1 && d_S2 && d_S3 && d_SX && d_MX && n_blocks >= 0 && n_genes > 0 && n_genes <= 64 * K1_MAX_SLICES);
   if (n_blocks == 0) return MM_OK;
   int32_t n_slices = (n_genes + 63) / 64;
   // enough workgroups to fill 256 CUs x 2 resident (64 KiB LDS each)
-  int split = (2048 + n_blocks - 1) / n_blocks;
+  int split = (K1_WGS + n_blocks - 1) / n_blocks;
   if (split < 1) split = 1;
   if (split > 64) split = 64;
   hipLaunchKernelGGL(k_moments1d_sell, dim3((unsigned)(n_blocks * split)), dim3(K1_THREADS), 0, (hipStream_t)stream,
