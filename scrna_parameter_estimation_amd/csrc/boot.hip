@@ -45,18 +45,24 @@ __global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict_
   }
   npyrng::Pcg64 g{st0, st1, st2, st3};
   const bool run = K >= 2;
+  // operands of the NEXT bin step are loaded while the current one computes (one lane = one latency-bound
+  // sequential chain, so an exposed L2/HBM round trip per step would be a large part of the step)
+  const int64_t obase = row0 * 64 + lane;
+  double c_pk = pk_[obase], c_lq = lq_[obase], c_v = v[obase], c_a = a[obase], c_b = b[obase];
   for (int r = 0; r < num_boot; r++) {
     double M1 = 0.0, M2 = 0.0;
     int32_t dn = n;
     bool live = true;
     for (int k = 0; k < kmax; k++) {
+      int kn = k + 1 < kmax ? k + 1 : 0;
+      int64_t on = obase + (int64_t)kn * 64;
+      double n_pk = pk_[on], n_lq = lq_[on], n_v = v[on], n_a = a[on], n_b = b[on];
       if (run && k < K) {
-        int64_t o = (row0 + k) * 64 + lane;
         int32_t w;
         if (k < K - 1) {
           w = 0;
           if (live) {
-            w = npyrng::binomial_pre<int32_t>(g, pk_[o], lq_[o], dn);
+            w = npyrng::binomial_pre<int32_t>(g, c_pk, c_lq, dn);
             dn -= w;
             if (dn <= 0) live = false;
           }
@@ -66,11 +72,11 @@ __global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict_
         if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = (int32_t)w;
         if (w != 0) {
           double wd = (double)w;
-          double bb = b[o], vv = v[o];
-          M1 += (vv * wd) * a[o];
-          M2 += ((vv * vv) * wd) * bb - ((omq * vv) * wd) * bb;
+          M1 += (c_v * wd) * c_a;
+          M2 += ((c_v * c_v) * wd) * c_b - ((omq * c_v) * wd) * c_b;
         }
       }
+      c_pk = n_pk; c_lq = n_lq; c_v = n_v; c_a = n_a; c_b = n_b;
     }
     if (run) {
       double mean = M1 / nobs;

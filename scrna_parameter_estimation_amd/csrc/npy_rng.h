@@ -185,6 +185,9 @@ NPY_HD Int binomial_inversion_pre(Pcg64 &g, Int n, double p, double lq) {
   Int X = 0;
   double px = qn;
   double U = pcg64_next_double(g);
+#ifdef NPY_ABLATE_INV_LOOP  // timing experiments only: wrong results
+  return (Int)(U > px);
+#endif
   while (U > px) {
     X++;
     bool over = false;
@@ -214,7 +217,11 @@ NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
   if (n == 0 || pk == 0.0) return 0;
   bool flip = !(pk <= 0.5);
   double p = flip ? 1.0 - pk : pk;
+#ifdef NPY_ABLATE_BTPE  // timing experiments only: wrong results
+  Int X = (p * (double)n <= 30.0) ? binomial_inversion_pre<Int>(g, n, p, lq) : (Int)((double)n * p);
+#else
   Int X = (p * (double)n <= 30.0) ? binomial_inversion_pre<Int>(g, n, p, lq) : binomial_btpe<Int>(g, n, p);
+#endif
   return flip ? n - X : X;
 }
 
