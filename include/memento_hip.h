@@ -166,6 +166,46 @@ int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_
                       const int32_t *d_test_gene, const double *d_W /* [n_tests][n_groups] */, const uint8_t *d_good /* [n_genes][n_groups] */,
                       int64_t n_tests, int32_t which, double *d_coef, double *d_stats, void *stream);
 
+/* ==== 2D (gene pairs) ===========================================================================
+ * K11 step 1: copy the columns of the n_cols genes with d_col_id[gene] = m >= 0 out of the SELL blocks into a
+ * gene-contiguous store: entries of (block b, column m) at d_out[col_ptr[b*(n_cols+1)+m] .. col_ptr[b*(n_cols+1)+m+1])
+ * (same packed uint32 entries; order inside a column is the storage order of the block). */
+int mm_extract_cols(const uint32_t *d_ent, const int64_t *d_blk_base, const int32_t *d_slice_w, const int32_t *d_slice_ptr,
+                    const int32_t *d_item_ptr, const int32_t *d_perm, int32_t n_blocks, int32_t n_genes, const int32_t *d_col_id,
+                    int32_t n_cols, const int64_t *d_col_ptr /* [nb][n_cols+1] */, uint32_t *d_out, void *stream);
+/* K11 step 2: prod[group][pair] = sum_c x_ci x_cj / sf_c^2
+ * replaces estimator._hyper_cov_relative sparse branch (X.multiply(Y).sum)  memento/estimator.py:225-228
+ * and the Gram product of _hyper_corr_symmetric  memento/estimator.py:253-255.
+ * Pairs are grouped by their left column: left l owns pairs [left_ptr[l], left_ptr[l+1]), right_col[pair] = partner
+ * column.  d_scratch: [n_blocks][n_pairs] fp64; d_out: [n_groups][n_pairs]. */
+int mm_pair_cross(const uint32_t *d_cols, const int64_t *d_col_ptr, int32_t n_cols, const int32_t *d_blk_cell0,
+                  const int32_t *d_grp_blk0, int32_t n_blocks, int32_t n_groups, const double *d_inv_sf, const int32_t *d_left_col,
+                  const int64_t *d_left_ptr, int32_t n_left, const int32_t *d_right_col, int64_t n_pairs, double *d_scratch,
+                  double *d_out, void *stream);
+/* 2D histograms: table of q = pair*n_groups + group is [n_sf_bins][xcap_i[q]][xcap_j[q]] uint32 at tab_ptr[q] (zeroed
+ * by the caller); counts the cells with x_j > 0.  replaces np.unique over two columns, memento/bootstrap.py:62-71 */
+int mm_pair_hist(const uint32_t *d_cols, const int64_t *d_col_ptr, int32_t n_cols, const int32_t *d_blk_cell0,
+                 const int32_t *d_blk_group, int32_t n_blocks, const uint8_t *d_sf_bin, const int32_t *d_left_col,
+                 const int64_t *d_left_ptr, int32_t n_left, const int32_t *d_right_col, int32_t n_groups, const int64_t *d_tab_ptr,
+                 const int32_t *d_xcap_i, const int32_t *d_xcap_j, uint32_t *d_tab, void *stream);
+/* x_j == 0 column from the left gene's 1D table (d_hist_i + hist_ptr[q], [n_sf_bins][xcap_i[q]], as completed by
+ * mm_bins_count) and the number of non-empty bins K[q]. */
+int mm_pair_bins_count(uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap_i, const int32_t *d_xcap_j,
+                       const uint32_t *d_hist_i, const int64_t *d_hist_ptr, int64_t n_q, int32_t n_sf_bins, int32_t *d_K,
+                       void *stream);
+/* replay order of the 2D bins: code = x_i*r1a + x_j*r1b + r0*approx_sf (bootstrap.py:62-65, two-column expr) */
+int mm_bins_order2d(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap_i, const int32_t *d_xcap_j,
+                    const int32_t *d_K, const int64_t *d_pair_list, int64_t n_list, int32_t big, int32_t n_groups, int32_t n_sf_bins,
+                    const double *d_sf_table, const double *d_r1a, const double *d_r1b, const double *d_r0,
+                    const int64_t *d_pair_slot, const int64_t *d_tile_ptr, const double *d_grp_ncells, double *d_pk, double *d_lq,
+                    double *d_v1, double *d_v2, double *d_a, double *d_b, int32_t *d_status, void *stream);
+/* 2D replay bootstrap: replicate covariance + the two variances folded into the correlation
+ * replaces bootstrap._bootstrap_2d + estimator._corr_from_cov   memento/bootstrap.py:119-157, estimator.py:273-292 */
+int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1, const double *d_v2, const double *d_a,
+                     const double *d_b, const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K,
+                     const double *d_slot_nobs, const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4],
+                     int32_t num_boot, int64_t ld, double *d_out_corr, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

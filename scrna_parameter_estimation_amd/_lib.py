@@ -51,6 +51,15 @@ _SIGS = {
                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "mm_boot_fill_log": ([c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_double), c_int32, c_uint64,
                           c_void_p, c_void_p], ctypes.c_int),
+    "mm_extract_cols": ([c_void_p] * 6 + [c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_pair_cross": ([c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                       c_void_p, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_pair_hist": ([c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_pair_bins_count": ([c_void_p] * 6 + [c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "mm_bins_order2d": ([c_void_p] * 6 + [c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 15, ctypes.c_int),
+    "mm_boot2d_replay": ([c_void_p] * 7 + [c_int64] + [c_void_p] * 4 + [ctypes.POINTER(c_uint64), c_int32, c_int64, c_void_p, c_void_p],
+                         ctypes.c_int),
     "mm_contract_stats": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                            c_void_p, c_void_p, c_void_p], ctypes.c_int),
 }

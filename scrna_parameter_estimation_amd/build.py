@@ -19,6 +19,7 @@ SOURCES = [
     ("hist.hip", ["-ffp-contract=off"]),
     ("boot.hip", ["-ffp-contract=off"]),
     ("contract.hip", []),
+    ("pairs.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # experiment hook: extra -D flags for kernel tuning (e.g. MM_EXTRA_DEFS="-DK1_UNROLL=8 -DMM_ITEM_ROWS=32")

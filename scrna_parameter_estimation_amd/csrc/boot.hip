@@ -167,6 +167,80 @@ __global__ __launch_bounds__(256) void k_boot_fill_log(double *__restrict__ mean
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2D replay: same multinomial chain over the (x_i, x_j, sf_bin) bins of a gene pair; per replicate the
+// covariance and the two variances (bootstrap.py:141-155, estimator.py:214-218, :171-174) are folded
+// into the correlation exactly as estimator._corr_from_cov does (:281-292: 5.0 sentinel where a variance
+// is <= 0, then clip to [-1, 1]).  Writes corr_b to out[row*ld + 1 + b].
+__global__ __launch_bounds__(256) void k_boot2d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
+                                                       const double *__restrict__ v1_, const double *__restrict__ v2_,
+                                                       const double *__restrict__ a, const double *__restrict__ b,
+                                                       const int64_t *__restrict__ tile_ptr, int64_t n_tiles,
+                                                       const int32_t *__restrict__ slot_K, const double *__restrict__ slot_nobs,
+                                                       const double *__restrict__ slot_omq, const int64_t *__restrict__ slot_row,
+                                                       uint64_t st0, uint64_t st1, uint64_t st2, uint64_t st3, int32_t num_boot,
+                                                       int64_t ld, double *__restrict__ out_corr) {
+  int lane = mm_lane();
+  int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (tile >= n_tiles) return;
+  int64_t slot = tile * 64 + lane;
+  int K = slot_K[slot];
+  int64_t row = slot_row[slot];
+  if (K <= 0 || row < 0) K = 0;
+  int64_t row0 = tile_ptr[tile];
+  int kmax = (int)(tile_ptr[tile + 1] - row0);
+  double nobs = slot_nobs[slot];
+  double omq = slot_omq[slot];
+  int32_t n = (int32_t)nobs;
+  double *oc = out_corr + row * ld + 1;
+  npyrng::Pcg64 g{st0, st1, st2, st3};
+  const bool run = K >= 1;
+  const int64_t obase = row0 * 64 + lane;
+  for (int r = 0; r < num_boot; r++) {
+    double A1 = 0.0, A2 = 0.0, MX = 0.0, Q1 = 0.0, Q2 = 0.0;
+    int32_t dn = n;
+    bool live = true;
+    for (int k = 0; k < kmax; k++) {
+      if (run && k < K) {
+        int64_t o = obase + (int64_t)k * 64;
+        int32_t w;
+        if (k < K - 1) {
+          w = 0;
+          if (live) {
+            w = npyrng::binomial_pre<int32_t>(g, pk_[o], lq_[o], dn);
+            dn -= w;
+            if (dn <= 0) live = false;
+          }
+        } else {
+          w = dn > 0 ? dn : 0;
+        }
+        if (w != 0) {
+          double wd = (double)w, x1 = v1_[o], x2 = v2_[o], aa = a[o], bb = b[o];
+          A1 += (x1 * wd) * aa;
+          A2 += (x2 * wd) * aa;
+          MX += ((x1 * x2) * wd) * bb;
+          Q1 += ((x1 * x1) * wd) * bb - ((omq * x1) * wd) * bb;
+          Q2 += ((x2 * x2) * wd) * bb - ((omq * x2) * wd) * bb;
+        }
+      }
+    }
+    if (run) {
+      double m1 = A1 / nobs, m2 = A2 / nobs;
+      double cov = MX / nobs - m1 * m2;
+      double var1 = Q1 / nobs - m1 * m1;
+      double var2 = Q2 / nobs - m2 * m2;
+      double corr = 5.0;
+      if (var1 > 0.0 && var2 > 0.0) {
+        double vp = sqrt(var1 * var2);
+        if (isfinite(vp)) corr = cov / vp;
+      }
+      if (corr > 1.0) corr = 1.0;
+      if (corr < -1.0) corr = -1.0;
+      oc[r] = corr;
+    }
+  }
+}
+
 extern "C" {
 
 int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
@@ -192,6 +266,21 @@ int mm_boot_fill_log(double *d_mean, double *d_var, int64_t n_rows, int64_t ld, 
   int64_t blocks = (n_rows + 3) / 4;
   hipLaunchKernelGGL(k_boot_fill_log, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_mean, d_var, n_rows, ld, num_boot,
                      mv_fit[0], mv_fit[1], mv_fit[2], fill_mode, fill_seed, d_n_invalid);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1, const double *d_v2, const double *d_a,
+                     const double *d_b, const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K,
+                     const double *d_slot_nobs, const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4],
+                     int32_t num_boot, int64_t ld, double *d_out_corr, void *stream) {
+  MM_ARG(d_pk && d_lq && d_v1 && d_v2 && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
+  MM_ARG(d_out_corr && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_tiles == 0) return MM_OK;
+  int64_t blocks = (n_tiles + 3) / 4;
+  hipLaunchKernelGGL(k_boot2d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
+                     d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
+                     pcg_state[3], num_boot, ld, d_out_corr);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -223,6 +223,124 @@ __global__ __launch_bounds__(NT) void k_bins_order(const uint32_t *__restrict__ 
   if (tie) atomicOr(status, 8);  // np.unique would merge these two bins; caller must handle (never seen in practice)
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2D variant: bins over (x_i, x_j, sf_bin) of a gene pair; code = x_i*r[0] + x_j*r[1] + r0*approx_sf
+// (bootstrap.py:62-65 with a two-column expr).  Table layout [sf_bin][x_i][x_j].
+template <int CAP, int NT>
+__global__ __launch_bounds__(NT) void k_bins_order2d(const uint32_t *__restrict__ tab, const int64_t *__restrict__ tab_ptr,
+                                                     const int32_t *__restrict__ xcap_i, const int32_t *__restrict__ xcap_j,
+                                                     const int32_t *__restrict__ Karr, const int64_t *__restrict__ pair_list,
+                                                     int64_t n_list, int32_t n_groups, int32_t n_sf_bins,
+                                                     const double *__restrict__ sf_table, const double *__restrict__ r1a,
+                                                     const double *__restrict__ r1b, const double *__restrict__ r0a,
+                                                     const int64_t *__restrict__ pair_slot, const int64_t *__restrict__ tile_ptr,
+                                                     const double *__restrict__ grp_ncells, double *__restrict__ o_pk,
+                                                     double *__restrict__ o_lq, double *__restrict__ o_v1, double *__restrict__ o_v2,
+                                                     double *__restrict__ o_a, double *__restrict__ o_b, int32_t *__restrict__ status) {
+  extern __shared__ double smem_d[];
+  double *code = smem_d;                              // [CAP]
+  uint64_t *pay = (uint64_t *)(code + CAP);           // [CAP]  sf_bin << 40 | x_i << 20 | x_j
+  uint32_t *mult = (uint32_t *)(pay + CAP);           // [CAP]
+  __shared__ int n_found;
+  if (blockIdx.x >= n_list) return;
+  int64_t p = pair_list[blockIdx.x];
+  int64_t slot = pair_slot[p];
+  if (slot < 0) return;
+  int K = Karr[p];
+  if (K > CAP) {
+    if (threadIdx.x == 0) atomicOr(status, 2);
+    return;
+  }
+  int grp = (int)(p % n_groups);
+  int64_t tp = tab_ptr[p];
+  int ci = xcap_i[p], cj = xcap_j[p];
+  double ra = r1a[p], rb = r1b[p], r0 = r0a[p];
+  int tid = threadIdx.x;
+  for (int i = tid; i < CAP; i += NT) code[i] = INFINITY;
+  if (tid == 0) n_found = 0;
+  __syncthreads();
+  if (tid < 64) {
+    int total = n_sf_bins * ci * cj;
+    int pos = 0;
+    for (int i0 = 0; i0 < total; i0 += 64) {
+      int i = i0 + tid;
+      uint32_t c = i < total ? tab[tp + i] : 0u;
+      unsigned long long m = __ballot(c != 0);
+      if (c != 0) {
+        int at = pos + __popcll(m & ((1ull << tid) - 1ull));
+        if (at < CAP) {
+          uint32_t xj = (uint32_t)(i % cj), xi = (uint32_t)((i / cj) % ci), bin = (uint32_t)(i / (cj * ci));
+          double c1 = (double)xi * ra;
+          double c2 = (double)xj * rb;
+          double cs = r0 * sf_table[bin];
+          code[at] = (c1 + c2) + cs;
+          pay[at] = ((uint64_t)bin << 40) | ((uint64_t)xi << 20) | (uint64_t)xj;
+          mult[at] = c;
+        }
+      }
+      pos += __popcll(m);
+    }
+    if (tid == 0) n_found = pos;
+  }
+  __syncthreads();
+  if (n_found != K) {
+    if (tid == 0) atomicOr(status, 4);
+    return;
+  }
+  int n = 1;
+  while (n < K) n <<= 1;
+  for (int k2 = 2; k2 <= n; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n; i += NT) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          bool up = (i & k2) == 0;
+          double a_ = code[i], b_ = code[ixj];
+          if ((a_ > b_) == up && a_ != b_) {
+            code[i] = b_;
+            code[ixj] = a_;
+            uint64_t tpay = pay[i];
+            pay[i] = pay[ixj];
+            pay[ixj] = tpay;
+            uint32_t tm = mult[i];
+            mult[i] = mult[ixj];
+            mult[ixj] = tm;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int64_t tile = slot >> 6, ln = slot & 63;
+  int64_t row0 = tile_ptr[tile];
+  double N = grp_ncells[grp];
+  bool tie = false;
+  for (int k = tid; k + 1 < K; k += NT)
+    if (code[k] == code[k + 1]) tie = true;
+  __syncthreads();
+  if (tid == 0) {
+    double rem = 1.0;
+    for (int k = 0; k < K; k++) {
+      code[k] = rem;
+      rem -= (double)mult[k] / N;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += NT) {
+    uint32_t bin = (uint32_t)(pay[k] >> 40), xi = (uint32_t)((pay[k] >> 20) & 0xFFFFFu), xj = (uint32_t)(pay[k] & 0xFFFFFu);
+    double sf = sf_table[bin];
+    double pk = ((double)mult[k] / N) / code[k];
+    int64_t o = (row0 + k) * 64 + ln;
+    o_pk[o] = pk;
+    o_lq[o] = npyrng::binomial_lq(pk);
+    o_v1[o] = (double)xi;
+    o_v2[o] = (double)xj;
+    o_a[o] = 1.0 / sf;
+    o_b[o] = 1.0 / (sf * sf);
+  }
+  if (tie) atomicOr(status, 8);
+}
+
 extern "C" {
 
 int mm_hist1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const int32_t *d_slice_w, const int32_t *d_slice_ptr,
@@ -275,6 +393,32 @@ int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t
     hipLaunchKernelGGL((k_bins_order<CAP, NT>), dim3((unsigned)n_list), dim3(NT), shm, (hipStream_t)stream, d_tab, d_tab_ptr, d_xcap,
                        d_K, d_pair_list, n_list, n_groups, n_sf_bins, d_sf_table, d_r1, d_r0, d_pair_slot, d_tile_ptr, d_grp_ncells,
                        d_pk, d_lq, d_v, d_a, d_b, d_status);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_bins_order2d(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap_i, const int32_t *d_xcap_j,
+                    const int32_t *d_K, const int64_t *d_pair_list, int64_t n_list, int32_t big, int32_t n_groups, int32_t n_sf_bins,
+                    const double *d_sf_table, const double *d_r1a, const double *d_r1b, const double *d_r0,
+                    const int64_t *d_pair_slot, const int64_t *d_tile_ptr, const double *d_grp_ncells, double *d_pk, double *d_lq,
+                    double *d_v1, double *d_v2, double *d_a, double *d_b, int32_t *d_status, void *stream) {
+  MM_ARG(d_tab && d_tab_ptr && d_xcap_i && d_xcap_j && d_K && d_pair_list && d_sf_table && d_r1a && d_r1b && d_r0 && d_pair_slot);
+  MM_ARG(d_tile_ptr && d_grp_ncells && d_pk && d_lq && d_v1 && d_v2 && d_a && d_b && d_status && n_list >= 0 && n_sf_bins <= 256);
+  if (n_list == 0) return MM_OK;
+  if (!big) {
+    constexpr int CAP = 1024, NT = 64;
+    size_t shm = (size_t)CAP * 20;
+    hipLaunchKernelGGL((k_bins_order2d<CAP, NT>), dim3((unsigned)n_list), dim3(NT), shm, (hipStream_t)stream, d_tab, d_tab_ptr, d_xcap_i,
+                       d_xcap_j, d_K, d_pair_list, n_list, n_groups, n_sf_bins, d_sf_table, d_r1a, d_r1b, d_r0, d_pair_slot, d_tile_ptr,
+                       d_grp_ncells, d_pk, d_lq, d_v1, d_v2, d_a, d_b, d_status);
+  } else {
+    constexpr int CAP = 8192, NT = 512;
+    size_t shm = (size_t)CAP * 20;
+    MM_HIP(hipFuncSetAttribute((const void *)k_bins_order2d<CAP, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((k_bins_order2d<CAP, NT>), dim3((unsigned)n_list), dim3(NT), shm, (hipStream_t)stream, d_tab, d_tab_ptr, d_xcap_i,
+                       d_xcap_j, d_K, d_pair_list, n_list, n_groups, n_sf_bins, d_sf_table, d_r1a, d_r1b, d_r0, d_pair_slot, d_tile_ptr,
+                       d_grp_ncells, d_pk, d_lq, d_v1, d_v2, d_a, d_b, d_status);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;

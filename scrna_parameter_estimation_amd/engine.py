@@ -178,7 +178,8 @@ class CountBlocks:
         self.ent = zeros((max(1, self.total_rows) * 256,), torch.int32)
         _lib.call("mm_sell_scatter", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
                   P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), s)
-        self.nnz_sel = int(host(blk_cnt, np.uint16).astype(np.int64).sum())
+        self.blk_cnt = host(blk_cnt, np.uint16)            # nnz per (block, gene), host copy [nb][G]
+        self.nnz_sel = int(self.blk_cnt.astype(np.int64).sum())
         del blk_cnt
         # slab for K1 partial sums (reused across calls)
         n = max(1, self.total_items) * 64
@@ -215,6 +216,44 @@ class CountBlocks:
                   P(self.item_ptr), P(self.blk_item_base), P(self.d_grp_blk0), self.n_groups, self.G, P(out_S), P(out_sx),
                   P(out_mx), _stream())
         return host(out_S), host(out_sx, np.uint64), host(out_mx, np.uint32)
+
+
+def pack_lanes(K_sorted_desc, target_waves):
+    """Lane packing of sequential chains into 64-wide tiles.  ``K_sorted_desc``: steps of each chain, descending.
+
+    A chain is one sequential stream, so a wave costs about  K_max(lanes) x c(L)  with c(L) = C0 + C1*L
+    instructions per bin step (lanes diverge between the inversion and BTPE samplers).  Wide waves are the most
+    instruction-efficient, but the heaviest chain bounds the makespan; so every wave gets the same cost budget:
+    L(K) = largest lane count with K*c(L) <= budget, and the budget is chosen (bisection) to yield about
+    ``target_waves`` waves.  Returns (slot of every chain = tile*64 + lane, number of tiles)."""
+    Ks = np.asarray(K_sorted_desc, dtype=np.float64)
+    n_act = len(Ks)
+    if n_act == 0:
+        return np.zeros(0, dtype=np.int64), 0
+    C0, C1 = PACK_C0, PACK_C1
+
+    def lanes_for(budget):
+        return np.clip(np.floor((budget / np.maximum(Ks, 1.0) - C0) / C1), 1, 64)
+
+    lo_b, hi_b = C0 + C1, float(Ks.max()) * (C0 + 64 * C1) * 4.0
+    for _ in range(50):
+        mid = 0.5 * (lo_b + hi_b)
+        if (1.0 / lanes_for(mid)).sum() > target_waves:
+            lo_b = mid
+        else:
+            hi_b = mid
+    lanes = np.maximum.accumulate(lanes_for(hi_b).astype(np.int64))    # non-decreasing along the K-descending order
+    slot_of = np.zeros(n_act, dtype=np.int64)
+    n_tiles, pos = 0, 0
+    while pos < n_act:
+        L = int(lanes[pos])
+        run_end = int(np.searchsorted(lanes, L, side="right"))
+        cnt = run_end - pos
+        idx = np.arange(cnt)
+        slot_of[pos:run_end] = (n_tiles + idx // L) * 64 + idx % L
+        n_tiles += -(-cnt // L)
+        pos = run_end
+    return slot_of, n_tiles
 
 
 def pcg64_state(seed=5):
@@ -301,36 +340,7 @@ class Bootstrap1D:
             raise NotImplementedError(f"a (gene, group) pair has more than {ORDER_BIG_CAP} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         n_act = len(order)
-        # Lane packing.  A pair is one sequential stream, so a wave costs about  K_max(lanes) x c(L)  with
-        # c(L) = C0 + C1*L instructions per bin step (lanes diverge between the inversion and BTPE samplers).
-        # Wide waves are the most instruction-efficient, but the heaviest pair bounds the makespan; so give every
-        # wave the same cost budget: L(K) = largest lane count with K*c(L) <= budget, and pick the budget (bisection)
-        # that yields about ``target_waves`` waves (a few per SIMD on 256 CUs x 4 SIMDs).
-        Ks = self.K[order].astype(np.float64)
-        C0, C1 = PACK_C0, PACK_C1
-
-        def lanes_for(budget):
-            return np.clip(np.floor((budget / np.maximum(Ks, 1.0) - C0) / C1), 1, 64)
-
-        lo_b, hi_b = C0 + C1, float(Ks.max() if n_act else 1.0) * (C0 + 64 * C1) * 4.0
-        for _ in range(50):
-            mid = 0.5 * (lo_b + hi_b)
-            if (1.0 / lanes_for(mid)).sum() > target_waves:
-                lo_b = mid
-            else:
-                hi_b = mid
-        lanes = lanes_for(hi_b).astype(np.int64) if n_act else np.zeros(0, dtype=np.int64)
-        lanes = np.maximum.accumulate(lanes)     # non-decreasing along the K-descending order
-        slot_of = np.zeros(n_act, dtype=np.int64)
-        n_tiles, pos = 0, 0
-        while pos < n_act:                      # lanes[] is non-decreasing along the K-descending order
-            L = int(lanes[pos])
-            run_end = int(np.searchsorted(lanes, L, side="right"))
-            cnt = run_end - pos
-            idx = np.arange(cnt)
-            slot_of[pos:run_end] = (n_tiles + idx // L) * 64 + idx % L
-            n_tiles += -(-cnt // L)
-            pos = run_end
+        slot_of, n_tiles = pack_lanes(self.K[order], target_waves)
         self.n_tiles = n_tiles
         pair_slot = np.full(self.n_pairs, -1, dtype=np.int64)
         pair_slot[order] = slot_of
@@ -392,4 +402,177 @@ class Bootstrap1D:
         d_tg, d_W, d_good = dev(np.asarray(test_gene, dtype=np.int32)), dev(np.asarray(W, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
         _lib.call("mm_contract_stats", P(self.ym), P(self.yv), self.ld, self.B, self.ng, P(d_tg), P(d_W), P(d_good), n_tests,
                   int(which), P(coef), P(stats), _stream())
+        return coef, host(stats)[:n_tests]
+
+
+# =================================================================================================
+# 2D: gene pairs
+# =================================================================================================
+
+
+class GeneColumns:
+    """Gene-contiguous copy of the columns of ``genes`` (indices into the blocks' gene space), per block
+    (mm_extract_cols).  The pair kernels join two columns through a dense per-cell LDS vector."""
+
+    def __init__(self, blocks, genes):
+        torch = _torch()
+        self.blocks = blocks
+        self.genes = np.asarray(genes, dtype=np.int64)
+        M = self.n_cols = len(self.genes)
+        nb = blocks.n_blocks
+        lens = blocks.blk_cnt[:, self.genes].astype(np.int64)               # [nb][M]
+        ptr = np.zeros((nb, M + 1), dtype=np.int64)
+        flat = np.cumsum(lens.reshape(-1))
+        total = int(flat[-1]) if flat.size else 0
+        starts = np.concatenate([[0], flat[:-1]]).reshape(nb, M) if flat.size else np.zeros((nb, M), dtype=np.int64)
+        ptr[:, :M] = starts
+        ptr[:, M] = starts[:, -1] + lens[:, -1] if M else 0
+        self.col_ptr = dev(ptr)
+        col_id = np.full(blocks.G, -1, dtype=np.int32)
+        col_id[self.genes] = np.arange(M, dtype=np.int32)
+        d_col_id = dev(col_id)
+        self.cols = zeros((max(1, total),), torch.int32)
+        _lib.call("mm_extract_cols", P(blocks.ent), P(blocks.blk_base), P(blocks.slice_w), P(blocks.slice_ptr), P(blocks.item_ptr),
+                  P(blocks.perm), nb, blocks.G, P(d_col_id), M, P(self.col_ptr), P(self.cols), _stream())
+        self.slot_of_gene = {int(g): i for i, g in enumerate(self.genes)}
+
+
+def _group_pairs(col1, col2):
+    """Sort pairs by left column -> (order, left_col, left_ptr, right_col_sorted)."""
+    col1 = np.asarray(col1, dtype=np.int64)
+    col2 = np.asarray(col2, dtype=np.int64)
+    order = np.argsort(col1, kind="stable")
+    c1s = col1[order]
+    left_col, start = np.unique(c1s, return_index=True)
+    left_ptr = np.concatenate([start, [len(c1s)]]).astype(np.int64)
+    return order, left_col.astype(np.int32), left_ptr, col2[order].astype(np.int32)
+
+
+def pair_cross(cols, col1, col2, inv_sf_cells):
+    """prod[group][pair] = sum_c x_ci x_cj / sf_c^2 for pairs of column slots (K11).  Host array."""
+    torch = _torch()
+    b = cols.blocks
+    order, left_col, left_ptr, right = _group_pairs(col1, col2)
+    n_pairs = len(order)
+    d_inv = dev(np.asarray(inv_sf_cells, dtype=np.float64)[b.cell_order])
+    d_left, d_lptr, d_right = dev(left_col), dev(left_ptr), dev(right)
+    scratch = empty((b.n_blocks, max(1, n_pairs)), torch.float64)
+    out = empty((b.n_groups, max(1, n_pairs)), torch.float64)
+    _lib.call("mm_pair_cross", P(cols.cols), P(cols.col_ptr), cols.n_cols, P(b.d_blk_cell0), P(b.d_grp_blk0), b.n_blocks, b.n_groups,
+              P(d_inv), P(d_left), P(d_lptr), len(left_col), P(d_right), n_pairs, P(scratch), P(out), _stream())
+    res = np.empty((b.n_groups, n_pairs))
+    res[:, order] = host(out)[:, :n_pairs]
+    return res
+
+
+class Bootstrap2D:
+    """2D analogue of Bootstrap1D for a list of gene pairs (column slots of a GeneColumns store):
+    (x_i, x_j, sf_bin) histograms -> bins -> replay order -> replay bootstrap of the correlation."""
+
+    def __init__(self, cols, col1, col2, maxx, sf_bin_cells, sf_table, grp_q, num_boot):
+        torch = _torch()
+        self.cols = cols
+        b = self.blocks = cols.blocks
+        ng = self.ng = b.n_groups
+        self.B, self.ld = int(num_boot), int(num_boot) + 1
+        self.n_bins = len(sf_table)
+        self.sf_table = np.asarray(sf_table, dtype=np.float64)
+        self.grp_q = np.asarray(grp_q, dtype=np.float64)
+        self.order, left_col, left_ptr, right = _group_pairs(col1, col2)      # kernels see pairs in this order
+        self.n_pairs = len(self.order)
+        self.n_q = self.n_pairs * ng
+        s = _stream()
+        # 1D tables of every column (left genes need them for the x_j == 0 column)
+        self.h1 = Bootstrap1D(b, cols.genes, maxx, sf_bin_cells, sf_table, grp_q, num_boot)
+        c1s = np.asarray(col1, dtype=np.int64)[self.order]
+        c2s = np.asarray(col2, dtype=np.int64)[self.order]
+        q_left = (c1s[:, None] * ng + np.arange(ng)[None, :]).reshape(-1)
+        q_right = (c2s[:, None] * ng + np.arange(ng)[None, :]).reshape(-1)
+        xcap_i = self.h1.xcap[q_left].astype(np.int32)
+        xcap_j = self.h1.xcap[q_right].astype(np.int32)
+        sizes = self.n_bins * xcap_i.astype(np.int64) * xcap_j.astype(np.int64)
+        tab_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.d_xi, self.d_xj, self.d_tab_ptr = dev(xcap_i), dev(xcap_j), dev(tab_ptr[:-1])
+        self.tab = zeros((max(1, int(tab_ptr[-1])),), torch.int32)
+        bins_sorted = np.asarray(sf_bin_cells, dtype=np.uint8)[b.cell_order]
+        d_bins = dev(bins_sorted)
+        d_left, d_lptr, d_right = dev(left_col), dev(left_ptr), dev(right)
+        _lib.call("mm_pair_hist", P(cols.cols), P(cols.col_ptr), cols.n_cols, P(b.d_blk_cell0), P(b.d_blk_group), b.n_blocks, P(d_bins),
+                  P(d_left), P(d_lptr), len(left_col), P(d_right), ng, P(self.d_tab_ptr), P(self.d_xi), P(self.d_xj), P(self.tab), s)
+        d_hptr = dev(self.h1.tab_ptr[q_left])
+        self.d_K = empty((max(1, self.n_q),), torch.int32)
+        _lib.call("mm_pair_bins_count", P(self.tab), P(self.d_tab_ptr), P(self.d_xi), P(self.d_xj), P(self.h1.tab), P(d_hptr), self.n_q,
+                  self.n_bins, P(self.d_K), s)
+        self.K = host(self.d_K)[:self.n_q]
+        self.xcap_i, self.xcap_j, self.tab_ptr = xcap_i, xcap_j, tab_ptr
+
+    def bins_of(self, q):
+        t0 = int(self.tab_ptr[q])
+        ci, cj = int(self.xcap_i[q]), int(self.xcap_j[q])
+        tab = host(self.tab[t0:t0 + self.n_bins * ci * cj], np.uint32).reshape(self.n_bins, ci, cj)
+        bi, xi, xj = np.nonzero(tab)
+        return bi, xi, xj, tab[bi, xi, xj]
+
+    def run(self, skip, r1a, r1b, r0, true_corr, pcg_seed=5, target_waves=PACK_WAVES):
+        """All arrays are indexed by q = sorted_pair*n_groups + group (see ``self.order``).  Leaves the
+        replicate correlations in self.yc [n_q][B+1] (column 0 = true correlation)."""
+        torch = _torch()
+        s = _stream()
+        ng, B, ld = self.ng, self.B, self.ld
+        active = (~np.asarray(skip, dtype=bool)) & (self.K >= 1)
+        act = np.flatnonzero(active)
+        if len(act) and (self.K[act] > ORDER_BIG_CAP).any():
+            raise NotImplementedError(f"a (pair, group) has more than {ORDER_BIG_CAP} unique bins")
+        order = act[np.argsort(-self.K[act], kind="stable")]
+        slot_of, n_tiles = pack_lanes(self.K[order], target_waves)
+        pair_slot = np.full(self.n_q, -1, dtype=np.int64)
+        pair_slot[order] = slot_of
+        slot_pair = np.full(n_tiles * 64, -1, dtype=np.int64)
+        slot_pair[slot_of] = order
+        slot_K = np.zeros(n_tiles * 64, dtype=np.int32)
+        slot_K[slot_of] = self.K[order]
+        tile_k = slot_K.reshape(n_tiles, 64).max(axis=1) if n_tiles else np.zeros(0, dtype=np.int32)
+        tile_ptr = np.concatenate([[0], np.cumsum(tile_k.astype(np.int64))]).astype(np.int64)
+        rows = int(tile_ptr[-1])
+        self.draws_per_replicate = int(np.maximum(self.K[order] - 1, 0).sum())
+        ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(6)]
+        d_pair_slot, d_tile_ptr = dev(pair_slot), dev(tile_ptr)
+        status = zeros((1,), torch.int32)
+        d_ra, d_rb, d_r0 = dev(np.asarray(r1a, np.float64)), dev(np.asarray(r1b, np.float64)), dev(np.asarray(r0, np.float64))
+        d_sf, d_nc = dev(self.sf_table), dev(self.blocks.grp_ncells.astype(np.float64))
+        small = order[self.K[order] <= ORDER_SMALL_CAP]
+        big = order[self.K[order] > ORDER_SMALL_CAP]
+        for lst, is_big in ((small, 0), (big, 1)):
+            if len(lst):
+                d_lst = dev(lst)
+                _lib.call("mm_bins_order2d", P(self.tab), P(self.d_tab_ptr), P(self.d_xi), P(self.d_xj), P(self.d_K), P(d_lst), len(lst),
+                          is_big, ng, self.n_bins, P(d_sf), P(d_ra), P(d_rb), P(d_r0), P(d_pair_slot), P(d_tile_ptr), P(d_nc),
+                          *[P(o) for o in ops], P(status), s)
+        nobs = np.zeros(n_tiles * 64)
+        nobs[slot_of] = self.blocks.grp_ncells[order % ng]
+        omq = np.zeros(n_tiles * 64)
+        omq[slot_of] = 1.0 - self.grp_q[order % ng]
+        self.yc = torch.full((max(1, self.n_q), ld), float("nan"), dtype=torch.float64, device="cuda")
+        self.yc[: self.n_q, 0] = dev(np.asarray(true_corr, dtype=np.float64))
+        d_slot_K, d_nobs, d_omq, d_slot_pair = dev(slot_K), dev(nobs), dev(omq), dev(slot_pair)
+        if n_tiles:
+            _lib.call("mm_boot2d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
+                      pcg64_state(pcg_seed), B, ld, P(self.yc), s)
+        st = int(status.item())
+        if st & 6:
+            raise RuntimeError(f"mm_bins_order2d inconsistency (status {st})")
+        if st & 8:
+            raise NotImplementedError("two bins of one pair collided in the replay hash (np.unique would merge them)")
+        self.active = active
+        self.pair_slot = pair_slot
+
+    def contract(self, test_pair, W, good):
+        """K9/K10 on the correlation rows: tests (sorted pair index, weight row)."""
+        torch = _torch()
+        n_tests = len(test_pair)
+        coef = empty((max(1, n_tests), self.ld), torch.float64)
+        stats = empty((max(1, n_tests), 8), torch.float64)
+        d_tp, d_W, d_good = dev(np.asarray(test_pair, dtype=np.int32)), dev(np.asarray(W, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
+        _lib.call("mm_contract_stats", P(self.yc), P(self.yc), self.ld, self.B, self.ng, P(d_tp), P(d_W), P(d_good), n_tests, 0, P(coef),
+                  P(stats), _stream())
         return coef, host(stats)[:n_tests]

@@ -5,5 +5,6 @@
     memento.compute_1d_moments(adata); memento.ht_1d_moments(adata, covariate=..., treatment=..., resampling='bootstrap')
 """
 
-from .main import (setup_memento, create_groups, compute_1d_moments, ht_1d_moments, get_groups,  # noqa: F401
-                   get_1d_moments, get_1d_ht_result, prepare_to_save)
+from .main import (setup_memento, create_groups, compute_1d_moments, compute_2d_moments, ht_1d_moments,  # noqa: F401
+                   ht_2d_moments, get_1d_moments, get_2d_moments, get_1d_ht_result, get_2d_ht_result, prepare_to_save,
+                   get_corr_matrix, get_groups)

@@ -4,6 +4,7 @@
 Reference signatures mirrored (paths relative to /root/reference/):
   setup_memento        memento/main.py:26-34      create_groups      :94-99
   compute_1d_moments   :171-176                   ht_1d_moments      :341-350
+  compute_2d_moments   :293                       ht_2d_moments      :418-427      get_corr_matrix :277
   get_groups           :156-168                   get_1d_moments / get_1d_ht_result  :523, :635
 Extra keyword-only knobs (do not disturb the reference's positional order):
   ht_1d_moments(..., rng='replay', strict=False, fill_seed=0)
@@ -232,7 +233,7 @@ def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=Tru
     cur = st.gene_idx                                    # columns of the device blocks that adata currently holds
     mean = S[0][:, cur] / Nc[:, None]
     var = S[1][:, cur] / Nc[:, None] - (1 - gq)[:, None] * S[2][:, cur] / Nc[:, None] - mean ** 2
-    st.sumx, st.maxx = sumx, maxx
+    st.sumx, st.maxx, st.S = sumx, maxx, S
     obs_mean = sumx[:, cur].astype(np.float64) / Nc[:, None]                                   # main.py:201
     gene_filter = (obs_mean > m['filter_mean_thresh']) & (var > 0)                             # main.py:202-203
     gene_rv_filter = maxx[:, cur] >= 2                                                         # main.py:206-207
@@ -435,6 +436,175 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
 
 
 # ----------------------------------------------------------------------------------------------
+# 2D: compute_2d_moments / ht_2d_moments / get_corr_matrix
+# ----------------------------------------------------------------------------------------------
+
+
+def _corr_from_cov(cov, var_1, var_2):
+    """estimator._corr_from_cov (estimator.py:273-292): variances <= 0 become NaN (in place, as the
+    reference does), entries without a finite sqrt(v1 v2) keep the 5.0 sentinel and are then clipped to 1."""
+    corr = np.full(cov.shape, 5.0)
+    var_1[var_1 <= 0] = np.nan
+    var_2[var_2 <= 0] = np.nan
+    vp = np.sqrt(var_1 * var_2)
+    ok = np.isfinite(vp)
+    corr[ok] = cov[ok] / vp[ok]
+    corr[corr > 1] = 1
+    corr[corr < -1] = -1
+    return corr
+
+
+def compute_2d_moments(adata, gene_pairs, inplace=True):
+    """Covariance and correlation of the given gene pairs per group (reference: memento/main.py:293-338,
+    estimator.py:207-233).  The only O(nnz) quantity, sum_c x_i x_j / sf^2, comes from mm_pair_cross; the
+    means and the i == j correction reuse the 1D sums of compute_1d_moments."""
+    if not inplace:
+        adata = adata.copy()
+    m = adata.uns['memento']
+    st = m['_hip']
+    if 'size_factor' not in m.keys():
+        _bin_size_factor(adata)
+    groups = m['groups']
+    names = _var_names(adata)
+    mapping = dict(zip(names, np.arange(len(names))))
+    n_pairs = len(gene_pairs)
+    idx1 = np.array([mapping[a] for a, _ in gene_pairs], dtype=int)
+    idx2 = np.array([mapping[b] for _, b in gene_pairs], dtype=int)
+    m['2d_moments'] = {'gene_pairs': gene_pairs, 'gene_idx_1': idx1, 'gene_idx_2': idx2}
+    used = np.unique(np.concatenate([idx1, idx2])) if n_pairs else np.zeros(0, dtype=int)
+    st.cols = engine.GeneColumns(st.blocks, st.gene_idx[used])          # columns of the genes in the pair list
+    st.cols_local = used
+    slot = {int(g): i for i, g in enumerate(used)}
+    c1 = np.array([slot[int(i)] for i in idx1], dtype=np.int64)
+    c2 = np.array([slot[int(j)] for j in idx2], dtype=np.int64)
+    prod = engine.pair_cross(st.cols, c1, c2, 1.0 / adata.obs['memento_size_factor'].values)   # [n_groups][n_pairs]
+    Nc = st.blocks.grp_ncells.astype(np.float64)
+    same = idx1 == idx2
+    g1, g2 = st.gene_idx[idx1], st.gene_idx[idx2]
+    for gi, group in enumerate(groups):
+        q = m['group_q'][group]
+        p = prod[gi] / Nc[gi]
+        if same.any():
+            p[same] = p[same] - (1 - q) * st.S[2][gi, g1[same]] / Nc[gi]                       # estimator.py:229-230
+        cov = p - (st.S[0][gi, g1] / Nc[gi]) * (st.S[0][gi, g2] / Nc[gi])                      # estimator.py:231
+        var_1 = m['1d_moments'][group][1][idx1]
+        var_2 = m['1d_moments'][group][1][idx2]
+        corr = _corr_from_cov(cov, var_1, var_2)
+        m['2d_moments'][group] = {'cov': cov, 'corr': corr, 'var_1': var_1, 'var_2': var_2}
+    if not inplace:
+        return adata
+
+
+def get_corr_matrix(adata, group):
+    """All-by-all correlation matrix of one group (reference: memento/main.py:277-291,
+    estimator._hyper_corr_symmetric estimator.py:236-270)."""
+    m = adata.uns['memento']
+    st = m['_hip']
+    gi = m['groups'].index(group)
+    G = len(st.gene_idx)
+    cols = engine.GeneColumns(st.blocks, st.gene_idx)
+    iu, ju = np.triu_indices(G)
+    prod = engine.pair_cross(cols, iu, ju, 1.0 / adata.obs['memento_size_factor'].values)[gi]
+    n = float(st.blocks.grp_ncells[gi])
+    q = m['group_q'][group]
+    P = np.zeros((G, G))
+    P[iu, ju] = prod / n
+    P[ju, iu] = prod / n
+    d = np.arange(G)
+    P[d, d] -= (1 - q) * st.S[2][gi, st.gene_idx] / n                                          # estimator.py:256
+    mu = st.S[0][gi, st.gene_idx] / n
+    cov = P - np.outer(mu, mu)
+    var = m['1d_moments'][group][1]
+    var[var <= 0] = np.nan                                                                     # in place, like estimator.py:261
+    vp = np.sqrt(np.outer(var, var))
+    corr = np.full(cov.shape, 5.0)
+    ok = np.isfinite(vp)
+    corr[ok] = cov[ok] / vp[ok]
+    inside = (corr < 1.05) & (corr > -1.05)
+    corr[inside] = np.clip(corr[inside], a_min=-1, a_max=1)
+    corr[(corr > 1) | (corr < -1)] = np.nan
+    return corr
+
+
+def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=3, num_cpus=1,
+                  **kwargs):
+    """Bootstrap hypothesis test of correlation differences (reference: memento/main.py:418-520,
+    hypothesis_test._ht_2d :303-364).  Same replay semantics as ht_1d_moments."""
+    if 'resampling' not in kwargs:
+        raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
+    if kwargs['resampling'] != 'bootstrap' or kwargs.get('resample_rep', False) or treatment_for_gene is not None:
+        raise NotImplementedError("HIP path: resampling='bootstrap', resample_rep=False, treatment_for_gene=None")
+    approx = bool(kwargs.get('approx', False))
+    if not inplace:
+        adata = adata.copy()
+    m = adata.uns['memento']
+    st = m['_hip']
+    groups = m['groups']
+    ng = len(groups)
+    Nc_list = np.array([m['group_cells'][g].shape[0] for g in groups], dtype=np.float64)
+    cov = np.asarray(covariate.values, dtype=np.float64)
+    trt = np.asarray(treatment.values, dtype=np.float64)
+    gq = np.array([m['group_q'][g] for g in groups])
+    idx1, idx2 = m['2d_moments']['gene_idx_1'], m['2d_moments']['gene_idx_2']
+    n_conv = idx1.shape[0]
+    # unordered pairs, first appearance wins; self pairs skipped (main.py:467-482)
+    first, members = [], {}
+    for c in range(n_conv):
+        a, b = int(idx1[c]), int(idx2[c])
+        if a == b:
+            continue
+        key = frozenset((a, b))
+        if key in members:
+            members[key].append(c)
+            continue
+        members[key] = [c]
+        first.append(c)
+    first = np.asarray(first, dtype=np.int64)
+    P_ = len(first)
+    slot = {int(g): i for i, g in enumerate(st.cols_local)}
+    c1 = np.array([slot[int(idx1[c])] for c in first], dtype=np.int64)
+    c2 = np.array([slot[int(idx2[c])] for c in first], dtype=np.int64)
+    bs = engine.Bootstrap2D(st.cols, c1, c2, st.maxx, st.sf_bin, st.sf_table, gq, num_boot)
+    true_corr = np.stack([m['2d_moments'][g]['corr'][first] for g in groups], axis=1) if P_ else np.zeros((0, ng))   # [pair][group]
+    with np.errstate(invalid="ignore"):
+        skip = np.isnan(true_corr) | (np.abs(true_corr) == 1)                                  # hypothesis_test.py:325
+    live = ~skip.reshape(-1)
+    u = np.random.random(3 * int(live.sum()))            # r = random(2) then r0 = random() per live (pair, group), in order
+    r1a, r1b, r0 = (np.zeros(P_ * ng) for _ in range(3))
+    r1a[live], r1b[live], r0[live] = u[0::3], u[1::3], u[2::3]
+    so = bs.order                                         # device pair order (sorted by left column)
+
+    def to_dev_order(a):
+        return a.reshape(P_, ng)[so].reshape(-1)
+
+    bs.run(to_dev_order(skip.reshape(-1)), to_dev_order(r1a), to_dev_order(r1b), to_dev_order(r0),
+           to_dev_order(np.where(skip, np.nan, true_corr).reshape(-1)))
+    good = bs.active.reshape(P_, ng)                      # device order
+    cache = {}
+    rows = []
+    for k in range(P_):
+        key = good[k].tobytes()
+        W = cache.get(key)
+        if W is None:
+            W = cache[key] = _design.weight_rows(cov, trt, Nc_list, good[k])[:1]
+        rows.append(W)
+    Wmat = np.concatenate(rows, axis=0) if rows else np.zeros((0, ng))
+    coef, stt = bs.contract(np.arange(P_), Wmat, good)
+    pvals = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
+    corr_coef, corr_se, corr_asl = (np.full(n_conv, np.nan) for _ in range(3))
+    for k in range(P_):
+        c = int(first[so[k]])
+        if not good[k].any():
+            continue
+        for cc in members[frozenset((int(idx1[c]), int(idx2[c])))]:
+            corr_coef[cc], corr_se[cc], corr_asl[cc] = stt[k, 0], stt[k, 1], pvals[k]
+    m['2d_ht'] = {'treatment': treatment, 'covariate': covariate, 'corr_coef': corr_coef, 'corr_se': corr_se, 'corr_asl': corr_asl}
+    st.last_bootstrap2d = bs
+    if not inplace:
+        return adata
+
+
+# ----------------------------------------------------------------------------------------------
 # getters
 # ----------------------------------------------------------------------------------------------
 
@@ -477,3 +647,25 @@ def prepare_to_save(adata, keep=False):
     for group in m['groups'] + ['all']:
         m['mv_regressor'].pop(group, None)
     m['group_cells'] = {g: v.shape for g, v in m['group_cells'].items()}
+
+
+def get_2d_moments(adata, groupby=None):
+    """Correlation table per group (reference: memento/main.py:585-632, groupby=None form)."""
+    m = adata.uns['memento']
+    df = pd.DataFrame(m['2d_moments']['gene_pairs'], columns=['gene_1', 'gene_2'])
+    cell_counts = {k: v.shape[0] for k, v in m['group_cells'].items()}
+    for group, val in m['2d_moments'].items():
+        if 'sg^' not in group:
+            continue
+        df[group] = val['corr']
+    if groupby is None:
+        return df, cell_counts
+    raise NotImplementedError("groupby aggregation is not implemented")
+
+
+def get_2d_ht_result(adata):
+    """DataFrame of correlation coefficients, standard errors and p-values (reference: memento/main.py:658-670)."""
+    m = adata.uns['memento']
+    df = pd.DataFrame(m['2d_moments']['gene_pairs'], columns=['gene_1', 'gene_2'])
+    df['corr_coef'], df['corr_se'], df['corr_pval'] = m['2d_ht']['corr_coef'], m['2d_ht']['corr_se'], m['2d_ht']['corr_asl']
+    return df

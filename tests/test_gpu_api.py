@@ -100,6 +100,32 @@ def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     assert np.median(np.abs(ht["var_se"][ok] / g["ht_var_se"][ok] - 1)) < 0.15
 
 
+def test_2d_moments_ht_and_corr_matrix_match_reference(api_small):
+    """compute_2d_moments / get_corr_matrix / ht_2d_moments against the real reference's outputs (the pair list
+    holds a self pair and a duplicated unordered pair)."""
+    g = api_small
+    memento, adata = _run_to_moments(g)
+    names = np.asarray(adata.var.index)
+    pairs = list(zip(names[g["pair_idx1"]].tolist(), names[g["pair_idx2"]].tolist()))
+    memento.compute_2d_moments(adata, pairs)
+    m = adata.uns["memento"]
+    for i, k in enumerate(m["groups"]):
+        np.testing.assert_allclose(m["2d_moments"][k]["cov"], g["cov2d"][i], rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(m["2d_moments"][k]["corr"], g["corr2d"][i], rtol=1e-8, equal_nan=True)
+    cov, trt = _design(memento, adata, g)
+    np.random.seed(int(g["ht_seed"]) + 1)
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=False)
+    ht = m["2d_ht"]
+    np.testing.assert_allclose(ht["corr_coef"], g["ht2_corr_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(ht["corr_se"], g["ht2_corr_se"], rtol=1e-8, equal_nan=True)
+    np.testing.assert_allclose(ht["corr_asl"], g["ht2_corr_asl"], rtol=1e-5, equal_nan=True)
+    df = memento.get_2d_ht_result(adata)
+    assert list(df.columns) == ["gene_1", "gene_2", "corr_coef", "corr_se", "corr_pval"]
+    cm = memento.get_corr_matrix(adata, m["groups"][0])
+    np.testing.assert_allclose(cm, g["corr_matrix_g0"], rtol=1e-8, atol=1e-12, equal_nan=True)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from scrna_parameter_estimation_amd import _lib
 
