@@ -168,6 +168,65 @@ __global__ __launch_bounds__(256) void k_boot_fill_log(double *__restrict__ mean
 }
 
 // ------------------------------------------------------------------------------------------------
+// FAST mode (rng='fast'): the same multinomial chain and replicate moments, but one lane = one REPLICATE and
+// one wave = 64 replicates of ONE (gene, group) pair.  Every lane of a wave walks the same bins, so the
+// operands are wave-uniform, lanes take the same sampler (inversion or BTPE) at each step, and pairs x
+// replicates give the chip millions of independent chains.  Each (pair, replicate) owns a PCG64 stream
+// derived from (seed, pair, replicate) -- NOT numpy's single stream: results are statistically equivalent
+// to the reference (same algorithm, different random numbers), not draw-for-draw identical.
+__device__ __forceinline__ uint64_t mix64b(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ pk_, const double *__restrict__ lq_,
+                                                     const double *__restrict__ v, const double *__restrict__ a,
+                                                     const double *__restrict__ b, const int64_t *__restrict__ tile_ptr,
+                                                     int64_t n_slots, const int32_t *__restrict__ slot_K,
+                                                     const double *__restrict__ slot_nobs, const double *__restrict__ slot_omq,
+                                                     const int64_t *__restrict__ slot_row, uint64_t seed, int32_t num_boot,
+                                                     int32_t chunks, int64_t ld, double *__restrict__ out_mean,
+                                                     double *__restrict__ out_var) {
+  int lane = mm_lane();
+  int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t slot = wid / chunks;
+  int chunk = (int)(wid % chunks);
+  if (slot >= n_slots) return;
+  int K = slot_K[slot];
+  int64_t row = slot_row[slot];
+  if (K < 2 || row < 0) return;  // K == 1 rows stay NaN (bootstrap.py:97-98)
+  int r = chunk * 64 + lane;
+  bool mine = r < num_boot;
+  int64_t obase = tile_ptr[slot >> 6] * 64 + (slot & 63);
+  double nobs = slot_nobs[slot], omq = slot_omq[slot];
+  int32_t n = (int32_t)nobs;
+  uint64_t h = mix64b(seed ^ mix64b((uint64_t)row * 0x100000001B3ull + (uint64_t)r));
+  npyrng::Pcg64 g{mix64b(h), mix64b(h + 1), mix64b(h + 2), mix64b(h + 3) | 1ull};
+  double M1 = 0.0, M2 = 0.0;
+  int32_t dn = n;
+  for (int k = 0; k < K; k++) {
+    int64_t o = obase + (int64_t)k * 64;   // wave-uniform address: one broadcast load
+    int32_t w;
+    if (k < K - 1) {
+      w = dn > 0 ? npyrng::binomial_pre<int32_t>(g, pk_[o], lq_[o], dn) : 0;
+      dn -= w;
+    } else {
+      w = dn > 0 ? dn : 0;
+    }
+    double wd = (double)w, vv = v[o], bb = b[o];
+    M1 += (vv * wd) * a[o];
+    M2 += ((vv * vv) * wd) * bb - ((omq * vv) * wd) * bb;
+  }
+  if (mine) {
+    double mean = M1 / nobs;
+    out_mean[row * ld + 1 + r] = mean;
+    out_var[row * ld + 1 + r] = M2 / nobs - mean * mean;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 2D replay: same multinomial chain over the (x_i, x_j, sf_bin) bins of a gene pair; per replicate the
 // covariance and the two variances (bootstrap.py:141-155, estimator.py:214-218, :171-174) are folded
 // into the correlation exactly as estimator._corr_from_cov does (:281-292: 5.0 sentinel where a variance
@@ -281,6 +340,23 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
   hipLaunchKernelGGL(k_boot2d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, ld, d_out_corr);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_boot1d_fast(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
+                   const int64_t *d_tile_ptr, int64_t n_slots, const int32_t *d_slot_K, const double *d_slot_nobs,
+                   const double *d_slot_omq, const int64_t *d_slot_row, uint64_t seed, int32_t num_boot, int64_t ld,
+                   double *d_out_mean, double *d_out_var, void *stream) {
+  MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row);
+  MM_ARG(d_out_mean && d_out_var && n_slots >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_slots == 0) return MM_OK;
+  int32_t chunks = (num_boot + 63) / 64;
+  int64_t waves = n_slots * chunks;
+  int64_t blocks = (waves + 3) / 4;
+  MM_ARG(blocks < 2147483647LL);
+  hipLaunchKernelGGL(k_boot1d_fast, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b, d_tile_ptr,
+                     n_slots, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, seed, num_boot, chunks, ld, d_out_mean, d_out_var);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -324,7 +324,8 @@ class Bootstrap1D:
         self.ym[:, 0] = dev(np.asarray(true_mean_log, dtype=np.float64))
         self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
 
-    def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0, target_waves=PACK_WAVES):
+    def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0, target_waves=PACK_WAVES,
+            fast=False):
         """Order bins, replay the bootstrap and fill/log for every pair >= ``first_pair`` that is not skipped.
 
         ``skip``[pair] bool; ``r1``/``r0``[pair] the two uniforms of bootstrap.py:62,65.  Rows below
@@ -340,7 +341,8 @@ class Bootstrap1D:
             raise NotImplementedError(f"a (gene, group) pair has more than {ORDER_BIG_CAP} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         n_act = len(order)
-        slot_of, n_tiles = pack_lanes(self.K[order], target_waves)
+        # replay: cost-model lane packing (one lane = one sequential chain); fast: dense 64-wide tiles (one WAVE per pair)
+        slot_of, n_tiles = pack_lanes(self.K[order], 1 if fast else target_waves)
         self.n_tiles = n_tiles
         pair_slot = np.full(self.n_pairs, -1, dtype=np.int64)
         pair_slot[order] = slot_of
@@ -374,7 +376,10 @@ class Bootstrap1D:
         self.kmax_dump = kmax_dump
         self.slot_pair, self.slot_K, self.pair_slot, self.tile_ptr = slot_pair, slot_K, pair_slot, tile_ptr
         d_slot_K, d_nobs, d_omq, d_slot_pair = dev(slot_K), dev(nobs), dev(omq), dev(slot_pair)
-        if n_tiles:
+        if n_tiles and fast:
+            _lib.call("mm_boot1d_fast", *[P(o) for o in ops], P(d_tile_ptr), n_tiles * 64, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
+                      int(fill_seed) & ((1 << 64) - 1), B, ld, P(self.ym), P(self.yv), s)
+        elif n_tiles:
             _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       pcg64_state(pcg_seed), B, ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, s)
         st = int(status.item())

@@ -100,6 +100,25 @@ def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     assert np.median(np.abs(ht["var_se"][ok] / g["ht_var_se"][ok] - 1)) < 0.15
 
 
+def test_ht_1d_fast_rng_statistically_equivalent(api_small):
+    """rng='fast': own RNG streams, replicate-parallel kernel.  Observed coefficients are RNG-independent (exact);
+    standard errors agree with the reference's within Monte-Carlo error; p-values are strongly concordant."""
+    g = api_small
+    memento, adata = _run_to_moments(g)
+    cov, trt = _design(memento, adata, g)
+    np.random.seed(int(g["ht_seed"]))
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=2000, num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=True, rng="fast", fill_seed=7)
+    ht = adata.uns["memento"]["1d_ht"]
+    np.testing.assert_allclose(ht["mean_coef"], g["ht_mean_coef"], rtol=1e-8, equal_nan=True)
+    np.testing.assert_allclose(ht["var_coef"], g["ht_var_coef"], rtol=1e-8, equal_nan=True)
+    ok = np.isfinite(g["ht_mean_se"])
+    rel = ht["mean_se"][ok] / g["ht_mean_se"][ok] - 1       # reference used B=300: ~4-5% MC error on an SE
+    assert abs(np.median(rel)) < 0.03 and np.percentile(np.abs(rel), 90) < 0.15
+    rel = ht["var_se"][ok] / g["ht_var_se"][ok] - 1
+    assert abs(np.median(rel)) < 0.05 and np.percentile(np.abs(rel), 90) < 0.25
+
+
 def test_2d_moments_ht_and_corr_matrix_match_reference(api_small):
     """compute_2d_moments / get_corr_matrix / ht_2d_moments against the real reference's outputs (the pair list
     holds a self pair and a duplicated unordered pair)."""
