@@ -140,6 +140,7 @@ int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t
 int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
                      const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
                      const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
+                     int32_t mean_only /* 1: estimator._mean_only_1p, replicates are [mean+1, 10] (estimator.py:188-204) */,
                      int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream);
 
 /* FAST mode of K6+K7: one lane = one replicate, one wave = 64 replicates of one pair; every (pair, replicate)
@@ -148,8 +149,8 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
  * identical.  n_slots = number of slots in the tile layout written by mm_bins_order (64 * n_tiles). */
 int mm_boot1d_fast(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
                    const int64_t *d_tile_ptr, int64_t n_slots, const int32_t *d_slot_K, const double *d_slot_nobs,
-                   const double *d_slot_omq, const int64_t *d_slot_row, uint64_t seed, int32_t num_boot, int64_t ld,
-                   double *d_out_mean, double *d_out_var, void *stream);
+                   const double *d_slot_omq, const int64_t *d_slot_row, uint64_t seed, int32_t num_boot, int32_t mean_only,
+                   int64_t ld, double *d_out_mean, double *d_out_var, void *stream);
 
 /* ---- K8: residual variance, invalid-replicate fill, log  ---------------------------------------
  * replaces estimator._residual_variance + hypothesis_test._fill + np.log

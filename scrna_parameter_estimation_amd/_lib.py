@@ -47,9 +47,9 @@ _SIGS = {
     "mm_hist1d_sell": ([c_void_p] * 9 + [c_int32, c_int32] + [c_void_p] * 5, ctypes.c_int),
     "mm_bins_count": ([c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_bins_order": ([c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 13, ctypes.c_int),
-    "mm_boot1d_replay": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [ctypes.POINTER(c_uint64), c_int32, c_int64,
+    "mm_boot1d_replay": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "mm_boot1d_fast": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [c_uint64, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_boot1d_fast": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_boot_fill_log": ([c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_double), c_int32, c_uint64,
                           c_void_p, c_void_p], ctypes.c_int),
     "mm_extract_cols": ([c_void_p] * 6 + [c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),

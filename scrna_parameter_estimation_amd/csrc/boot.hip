@@ -20,8 +20,8 @@ __global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict_
                                                        const int64_t *__restrict__ tile_ptr, int64_t n_tiles,
                                                        const int32_t *__restrict__ slot_K, const double *__restrict__ slot_nobs,
                                                        const double *__restrict__ slot_omq, const int64_t *__restrict__ slot_row, uint64_t st0, uint64_t st1,
-                                                       uint64_t st2, uint64_t st3, int32_t num_boot, int64_t ld,
-                                                       double *__restrict__ out_mean, double *__restrict__ out_var,
+                                                       uint64_t st2, uint64_t st3, int32_t num_boot, int32_t mean_only,
+                                                       int64_t ld, double *__restrict__ out_mean, double *__restrict__ out_var,
                                                        int32_t *__restrict__ w_dump, int32_t kmax_dump) {
   int lane = mm_lane();
   int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -81,6 +81,10 @@ __global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict_
     if (run) {
       double mean = M1 / nobs;
       double var = M2 / nobs - mean * mean;
+      if (mean_only) {  // estimator._mean_only_1p (estimator.py:188-204): [mean + 1, 10]
+        mean = mean + 1;
+        var = 10.0;
+      }
       om[r] = mean;
       ov[r] = var;
     }
@@ -187,8 +191,8 @@ __global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ 
                                                      int64_t n_slots, const int32_t *__restrict__ slot_K,
                                                      const double *__restrict__ slot_nobs, const double *__restrict__ slot_omq,
                                                      const int64_t *__restrict__ slot_row, uint64_t seed, int32_t num_boot,
-                                                     int32_t chunks, int64_t ld, double *__restrict__ out_mean,
-                                                     double *__restrict__ out_var) {
+                                                     int32_t mean_only, int32_t chunks, int64_t ld,
+                                                     double *__restrict__ out_mean, double *__restrict__ out_var) {
   int lane = mm_lane();
   int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t slot = wid / chunks;
@@ -221,8 +225,13 @@ __global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ 
   }
   if (mine) {
     double mean = M1 / nobs;
+    double var = M2 / nobs - mean * mean;
+    if (mean_only) {
+      mean = mean + 1;
+      var = 10.0;
+    }
     out_mean[row * ld + 1 + r] = mean;
-    out_var[row * ld + 1 + r] = M2 / nobs - mean * mean;
+    out_var[row * ld + 1 + r] = var;
   }
 }
 
@@ -305,14 +314,15 @@ extern "C" {
 int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
                      const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
                      const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
-                     int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream) {
+                     int32_t mean_only, int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump,
+                     void *stream) {
   MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   MM_ARG(d_out_mean && d_out_var && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
   int64_t blocks = (n_tiles + 3) / 4;
   hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2], pcg_state[3],
-                     num_boot, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump);
+                     num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -346,8 +356,8 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
 
 int mm_boot1d_fast(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
                    const int64_t *d_tile_ptr, int64_t n_slots, const int32_t *d_slot_K, const double *d_slot_nobs,
-                   const double *d_slot_omq, const int64_t *d_slot_row, uint64_t seed, int32_t num_boot, int64_t ld,
-                   double *d_out_mean, double *d_out_var, void *stream) {
+                   const double *d_slot_omq, const int64_t *d_slot_row, uint64_t seed, int32_t num_boot, int32_t mean_only,
+                   int64_t ld, double *d_out_mean, double *d_out_var, void *stream) {
   MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row);
   MM_ARG(d_out_mean && d_out_var && n_slots >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_slots == 0) return MM_OK;
@@ -356,7 +366,7 @@ int mm_boot1d_fast(const double *d_pk, const double *d_lq, const double *d_v, co
   int64_t blocks = (waves + 3) / 4;
   MM_ARG(blocks < 2147483647LL);
   hipLaunchKernelGGL(k_boot1d_fast, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b, d_tile_ptr,
-                     n_slots, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, seed, num_boot, chunks, ld, d_out_mean, d_out_var);
+                     n_slots, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, seed, num_boot, mean_only, chunks, ld, d_out_mean, d_out_var);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

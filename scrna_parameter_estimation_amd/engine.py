@@ -325,7 +325,7 @@ class Bootstrap1D:
         self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
 
     def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0, target_waves=PACK_WAVES,
-            fast=False):
+            fast=False, mean_only=False):
         """Order bins, replay the bootstrap and fill/log for every pair >= ``first_pair`` that is not skipped.
 
         ``skip``[pair] bool; ``r1``/``r0``[pair] the two uniforms of bootstrap.py:62,65.  Rows below
@@ -378,10 +378,10 @@ class Bootstrap1D:
         d_slot_K, d_nobs, d_omq, d_slot_pair = dev(slot_K), dev(nobs), dev(omq), dev(slot_pair)
         if n_tiles and fast:
             _lib.call("mm_boot1d_fast", *[P(o) for o in ops], P(d_tile_ptr), n_tiles * 64, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
-                      int(fill_seed) & ((1 << 64) - 1), B, ld, P(self.ym), P(self.yv), s)
+                      int(fill_seed) & ((1 << 64) - 1), B, int(mean_only), ld, P(self.ym), P(self.yv), s)
         elif n_tiles:
             _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
-                      pcg64_state(pcg_seed), B, ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, s)
+                      pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, s)
         st = int(status.item())
         if st & 2 or st & 4:
             raise RuntimeError(f"mm_bins_order inconsistency (status {st})")

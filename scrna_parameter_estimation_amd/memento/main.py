@@ -94,8 +94,8 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
         adata = adata.copy()
     assert adata.obs[q_column].max() < 1
     assert type(adata.X) == csr_matrix, 'please make sure that adata.X is a scipy CSR matrix'
-    if estimator_type != 'hyper_relative':
-        raise NotImplementedError("the HIP path implements estimator_type='hyper_relative'")
+    if estimator_type not in ('hyper_relative', 'mean_only'):
+        raise NotImplementedError("the HIP path implements estimator_type 'hyper_relative' and 'mean_only'")
     m = adata.uns['memento'] = {}
     m['q_column'] = q_column
     m['all_q'] = adata.obs[q_column].values.mean()
@@ -138,6 +138,8 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
     adata.obs['memento_size_factor'] = size_factor
     S, _, _ = blocks_all.moments(1.0 / size_factor)                           # main.py:86-90
     m['all_1d_moments'] = list(_moments_from_sums(S[:, 0], N, m['all_q']))
+    if estimator_type == 'mean_only':                                         # estimator.py:188-204
+        m['all_1d_moments'] = [m['all_1d_moments'][0] + 1, np.ones(G) * 10]
     if not inplace:
         return adata
 
@@ -233,6 +235,8 @@ def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=Tru
     cur = st.gene_idx                                    # columns of the device blocks that adata currently holds
     mean = S[0][:, cur] / Nc[:, None]
     var = S[1][:, cur] / Nc[:, None] - (1 - gq)[:, None] * S[2][:, cur] / Nc[:, None] - mean ** 2
+    if m['estimator_type'] == 'mean_only':                                                     # estimator.py:188-204
+        mean, var = mean + 1, np.ones(mean.shape) * 10
     st.sumx, st.maxx, st.S = sumx, maxx, S
     obs_mean = sumx[:, cur].astype(np.float64) / Nc[:, None]                                   # main.py:201
     gene_filter = (obs_mean > m['filter_mean_thresh']) & (var > 0)                             # main.py:202-203
@@ -338,6 +342,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         adata = adata.copy()
     m = adata.uns['memento']
     st = m['_hip']
+    mean_only = m['estimator_type'] == 'mean_only'
     groups = m['groups']
     ng = len(groups)
     names = _var_names(adata)
@@ -370,7 +375,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
 
     if not strict:
         draw_hash(0)
-        n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'))      # K6-K8
+        n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
         bad_fill = (n_inv < 0).any(axis=1)
     else:
         n_inv_all = np.zeros((n_pairs, 2), dtype=np.int32)
@@ -378,7 +383,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         while first < n_pairs:
             saved = np.random.get_state()
             draw_hash(first)
-            n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first)
+            n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first, mean_only=mean_only)
             n_inv_all[first:] = n_inv
             needs = np.flatnonzero((~skip[first:]) & ((n_inv > 0).any(axis=1))) + first
             if len(needs) == 0:
@@ -626,7 +631,27 @@ def get_1d_moments(adata, groupby=None):
             var_df[group] = np.log(val[2])
     if groupby is None:
         return mean_df, var_df, cell_counts
-    raise NotImplementedError("groupby aggregation is not implemented")
+    # cell-count weighted averages of the log moments over the groups whose label contains the key
+    # (reference: memento/main.py:544-582)
+    keys = adata.obs[groupby].astype(str).drop_duplicates().values if groupby != 'ALL' else ['sg']
+    gm, gv = pd.DataFrame({'gene': names}), pd.DataFrame({'gene': names})
+    for key in keys:
+        sm = sv = cm = cv = 0
+        for group, val in m['1d_moments'].items():
+            if group == 'all' or key not in group:
+                continue
+            with np.errstate(invalid="ignore", divide="ignore"):
+                lm, lv = np.log(val[0]), np.log(val[2])
+            lm[np.isnan(lm)] = 0
+            lv[np.isnan(lv)] = 0
+            sm = sm + lm * cell_counts[group]
+            cm = cm + (val[0] > 0) * cell_counts[group]
+            sv = sv + lv * cell_counts[group]
+            cv = cv + (val[2] > 0) * cell_counts[group]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            gm[groupby + '_' + key] = sm / cm
+            gv[groupby + '_' + key] = sv / cv
+    return gm.copy(), gv.copy()
 
 
 def get_1d_ht_result(adata):
@@ -664,7 +689,21 @@ def get_2d_moments(adata, groupby=None):
         df[group] = val['corr']
     if groupby is None:
         return df, cell_counts
-    raise NotImplementedError("groupby aggregation is not implemented")
+    keys = adata.obs[groupby].astype(str).drop_duplicates().values if groupby != 'ALL' else ['sg']
+    out = pd.DataFrame({'gene_1': df['gene_1'], 'gene_2': df['gene_2']})       # reference: memento/main.py:604-632
+    for key in keys:
+        sc = cc = 0
+        for group, val in m['2d_moments'].items():
+            if 'sg^' not in group or key not in group:
+                continue
+            c = val['corr'].copy()
+            valid = ~np.isnan(c)
+            c[~valid] = 0
+            sc = sc + c * cell_counts[group]
+            cc = cc + valid * cell_counts[group]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out[groupby + '_' + key] = sc / cc
+    return out.copy()
 
 
 def get_2d_ht_result(adata):

@@ -29,6 +29,11 @@ def api_approx():
 
 
 @pytest.fixture(scope="session")
+def api_meanonly():
+    return load_golden("api_meanonly")
+
+
+@pytest.fixture(scope="session")
 def internals_small():
     return load_golden("internals_small")
 

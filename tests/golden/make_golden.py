@@ -54,15 +54,16 @@ def _groups_dict(d, groups):
     return np.stack([np.asarray(d[g]) for g in groups])
 
 
-def api_case(name, n_cells, n_genes, density, n_cond, n_rep, seed, num_boot, ht_seed, approx, two_d_pairs=0):
+def api_case(name, n_cells, n_genes, density, n_cond, n_rep, seed, num_boot, ht_seed, approx, two_d_pairs=0,
+             estimator_type="hyper_relative"):
     adata = synth_adata(n_cells, n_genes, density, n_cond, n_rep, seed, dtype=np.float64)
     inp = dict(
         indptr=adata.X.indptr.copy(), indices=adata.X.indices.copy(), data=adata.X.data.copy(),
         shape=np.array(adata.X.shape), cond=adata.obs["cond"].values.copy(), rep=adata.obs["rep"].values.copy(),
         q=adata.obs["q"].values.copy(), gene_names=np.array(adata.var.index.tolist()),
     )
-    memento.setup_memento(adata, q_column="q")
-    out = {}
+    memento.setup_memento(adata, q_column="q", estimator_type=estimator_type)
+    out = {"estimator_type": np.array(estimator_type)}
     m = adata.uns["memento"]
     out["size_factor"] = adata.obs["memento_size_factor"].values.copy()
     out["all_q"] = np.float64(m["all_q"])
@@ -84,6 +85,11 @@ def api_case(name, n_cells, n_genes, density, n_cond, n_rep, seed, num_boot, ht_
     out["var"] = np.stack([m["1d_moments"][g][1] for g in groups])
     out["res_var"] = np.stack([m["1d_moments"][g][2] for g in groups])
     out["mv_regressor"] = np.asarray(m["mv_regressor"][groups[0]]).copy()
+    # groupby aggregation of the getters (main.py:544-582)
+    gm, gv = memento.get_1d_moments(adata, groupby="cond")
+    out["groupby_cols"] = np.array([c for c in gm.columns if c != "gene"])
+    out["groupby_mean"] = gm[[c for c in gm.columns if c != "gene"]].values.astype(float)
+    out["groupby_var"] = gv[[c for c in gv.columns if c != "gene"]].values.astype(float)
 
     # design: intercept covariate, binary treatment on cond (cond==last vs rest) -- rows follow uns groups
     gdf = memento.get_groups(adata)
@@ -114,6 +120,9 @@ def api_case(name, n_cells, n_genes, density, n_cond, n_rep, seed, num_boot, ht_
         memento.compute_2d_moments(adata, pairs)
         out["pair_idx1"] = i1
         out["pair_idx2"] = i2
+        g2 = memento.get_2d_moments(adata, groupby="cond")
+        out["groupby2d_cols"] = np.array([c for c in g2.columns if c not in ("gene_1", "gene_2")])
+        out["groupby2d"] = g2[[c for c in g2.columns if c not in ("gene_1", "gene_2")]].values.astype(float)
         out["cov2d"] = np.stack([m["2d_moments"][g]["cov"] for g in groups])
         out["corr2d"] = np.stack([m["2d_moments"][g]["corr"] for g in groups])
         np.random.seed(ht_seed + 1)
@@ -202,4 +211,6 @@ if __name__ == "__main__":
     internals_case("internals_small", ad, picks=[(0, 0), (3, 1), (7, 2), (11, 3), (20, 0)], num_boot=64, seed=100)
     api_case("api_approx", n_cells=2400, n_genes=100, density=0.15, n_cond=2, n_rep=3, seed=23,
              num_boot=200, ht_seed=5, approx=True)
+    api_case("api_meanonly", n_cells=1500, n_genes=90, density=0.15, n_cond=2, n_rep=2, seed=31,
+             num_boot=150, ht_seed=9, approx=True, estimator_type="mean_only")
     regress_asl_case("regress_asl", seed=5)

@@ -23,13 +23,13 @@ def _run_to_moments(g):
     from scrna_parameter_estimation_amd import memento
 
     adata = _adata_from_golden(g)
-    memento.setup_memento(adata, q_column="q")
+    memento.setup_memento(adata, q_column="q", estimator_type=str(g["estimator_type"]) if "estimator_type" in g else "hyper_relative")
     memento.create_groups(adata, label_columns=["cond", "rep"])
     memento.compute_1d_moments(adata, min_perc_group=0.7)
     return memento, adata
 
 
-@pytest.mark.parametrize("fx", ["api_small", "api_approx"])
+@pytest.mark.parametrize("fx", ["api_small", "api_approx", "api_meanonly"])
 def test_setup_and_moments(fx, request):
     g = request.getfixturevalue(fx)
     memento, adata = _run_to_moments(g)
@@ -51,8 +51,12 @@ def test_setup_and_moments(fx, request):
         np.testing.assert_array_equal(m["gene_rv_filter"][k], g["gene_rv_filter"][i])
         np.testing.assert_allclose(m["1d_moments"][k][0], g["mean"][i], rtol=1e-11)
         np.testing.assert_allclose(m["1d_moments"][k][1], g["var"][i], rtol=1e-9, atol=1e-13)
-        np.testing.assert_allclose(m["1d_moments"][k][2], g["res_var"][i], rtol=1e-8, equal_nan=True)
-        np.testing.assert_allclose(m["mv_regressor"][k], g["mv_regressor"], rtol=1e-8)
+        np.testing.assert_allclose(m["1d_moments"][k][2], g["res_var"][i], rtol=1e-8, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(m["mv_regressor"][k], g["mv_regressor"], rtol=1e-8, atol=1e-12)
+    gm, gv = memento.get_1d_moments(adata, groupby="cond")          # cell-count weighted groupby aggregation
+    assert [c for c in gm.columns if c != "gene"] == list(g["groupby_cols"])
+    np.testing.assert_allclose(gm[list(g["groupby_cols"])].values, g["groupby_mean"], rtol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(gv[list(g["groupby_cols"])].values, g["groupby_var"], rtol=1e-7, atol=1e-12, equal_nan=True)
 
 
 def _design(memento, adata, g):
@@ -62,7 +66,7 @@ def _design(memento, adata, g):
     return cov, trt
 
 
-@pytest.mark.parametrize("fx", ["api_small", "api_approx"])
+@pytest.mark.parametrize("fx", ["api_small", "api_approx", "api_meanonly"])
 def test_ht_1d_strict_replay_matches_reference(fx, request):
     """strict=True replays the reference's global np.random stream (num_cpus=1 semantics): coefficients,
     standard errors and p-values must match the real reference's output."""
@@ -75,7 +79,9 @@ def test_ht_1d_strict_replay_matches_reference(fx, request):
     ht = adata.uns["memento"]["1d_ht"]
     for k in ["mean_coef", "mean_se", "var_coef", "var_se"]:
         np.testing.assert_allclose(ht[k], g["ht_" + k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg=k)
-    for k in ["mean_asl", "var_asl"]:
+    # mean_only fixes every variance at 10, so its "variability" statistics are ~1e-16 rounding noise in the
+    # reference as well (p-values of noise): only the DE p-values are meaningful there.
+    for k in (["mean_asl"] if fx == "api_meanonly" else ["mean_asl", "var_asl"]):
         np.testing.assert_allclose(ht[k], g["ht_" + k], rtol=1e-5, atol=1e-12, equal_nan=True, err_msg=k)
     df = memento.get_1d_ht_result(adata)
     assert list(df.columns) == ["gene", "tx", "de_coef", "de_se", "de_pval", "dv_coef", "dv_se", "dv_pval"]
@@ -141,6 +147,8 @@ def test_2d_moments_ht_and_corr_matrix_match_reference(api_small):
     np.testing.assert_allclose(ht["corr_asl"], g["ht2_corr_asl"], rtol=1e-5, equal_nan=True)
     df = memento.get_2d_ht_result(adata)
     assert list(df.columns) == ["gene_1", "gene_2", "corr_coef", "corr_se", "corr_pval"]
+    g2 = memento.get_2d_moments(adata, groupby="cond")
+    np.testing.assert_allclose(g2[list(g["groupby2d_cols"])].values, g["groupby2d"], rtol=1e-8, equal_nan=True)
     cm = memento.get_corr_matrix(adata, m["groups"][0])
     np.testing.assert_allclose(cm, g["corr_matrix_g0"], rtol=1e-8, atol=1e-12, equal_nan=True)
 

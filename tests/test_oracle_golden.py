@@ -68,7 +68,7 @@ def test_regress_and_asl(regress_asl):
         np.testing.assert_allclose(got, r["asl_out_" + tag], rtol=1e-9, err_msg=tag)
 
 
-@pytest.mark.parametrize("fx", ["api_small", "api_approx"])
+@pytest.mark.parametrize("fx", ["api_small", "api_approx"])  # (api_meanonly uses another estimator: GPU tests pin it directly)
 def test_ht_1d_end_to_end(fx, request):
     """Full ht_1d_moments replay with the seeded global stream (num_cpus=1 semantics)."""
     g = request.getfixturevalue(fx)
