@@ -205,8 +205,15 @@ def main():
         k1_ms = ms.value / reps
         nbytes = blocks.moments_bytes()
         achieved = nbytes / (k1_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_k1_traffic_C3.json")
+        if args.config == "C3" and os.path.exists(tfile):
+            # PMC counters cannot be read from inside this process: this is the figure recorded with
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction) on the same
+            # shape and kernel -- see profiles/README.md
+            traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
         roof = {"kernel": "k_moments1d_sell", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(nbytes),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": int(nbytes),
                 "ms_per_launch": round(k1_ms, 4), "nnz": int(blocks.nnz_sel)}
         bs = state.last_bootstrap
         # time one replay launch by itself (HIP events on the launch stream)

@@ -14,7 +14,10 @@
 #include "mm_common.h"
 #include "npy_rng.h"
 
-__global__ __launch_bounds__(256) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
+#ifndef BOOT_MIN_WAVES
+#define BOOT_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, BOOT_MIN_WAVES) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v, const double *__restrict__ a,
                                                        const double *__restrict__ b,
                                                        const int64_t *__restrict__ tile_ptr, int64_t n_tiles,

@@ -1,0 +1,91 @@
+"""Size-independent properties of the HIP path at a BASELINE-sized problem (config C2 shape: 100k cells x 20k
+genes, 5 % nnz, 8 groups), where the oracle would take too long: invariants the domain offers."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+
+    import bench
+    from scrna_parameter_estimation_amd import engine
+
+    cfg = dict(bench.CONFIGS["C2"])
+    csr = bench.synth_device_csr(cfg, 77, torch)
+    rng = np.random.default_rng(5)
+    gid = rng.integers(-1, 8, size=cfg["cells"]).astype(np.int32)
+    blocks = engine.CountBlocks(csr, gid, 8)
+    sf = rng.lognormal(0, 0.3, size=cfg["cells"])
+    return engine, torch, csr, gid, blocks, sf
+
+
+def test_ingest_conserves_counts(big):
+    engine, torch, csr, gid, blocks, sf = big
+    # every selected non-zero lands in exactly one block entry: nnz and total counts are conserved
+    rows = torch.repeat_interleave(torch.arange(csr.shape[0], device="cuda"), csr.indptr[1:] - csr.indptr[:-1])
+    sel = torch.from_numpy(gid >= 0).cuda()[rows]
+    assert blocks.nnz_sel == int(sel.sum().item())
+    ent = blocks.ent.view(torch.int32)
+    x = (ent >> 13) & 0x7FFFF
+    assert int((x != 0).sum().item()) == blocks.nnz_sel
+    assert int(x.to(torch.int64).sum().item()) == int(csr.data[sel].to(torch.int64).sum().item())
+    # padding stays below 6 % of the stored entries
+    assert blocks.total_rows * 256 <= 1.06 * blocks.nnz_sel + 256 * blocks.n_blocks * blocks.n_slices
+
+
+def test_moments_scaling_linearity_and_determinism(big):
+    engine, torch, csr, gid, blocks, sf = big
+    S, sumx, maxx = blocks.moments(1.0 / sf)
+    S2, sumx2, maxx2 = blocks.moments(1.0 / sf)
+    assert np.array_equal(S, S2) and np.array_equal(sumx, sumx2)          # fixed reduction order: bitwise repeatable
+    c = 4.0                                                                # power of two: exact scaling
+    Sc, _, _ = blocks.moments(1.0 / (sf * c))
+    np.testing.assert_array_equal(Sc[0], S[0] / c)
+    np.testing.assert_array_equal(Sc[1], S[1] / c ** 2)
+    np.testing.assert_array_equal(Sc[2], S[2] / c ** 2)
+    # sum over groups of sum_x equals the column sums of the selected rows; max over groups = column max
+    rows = torch.repeat_interleave(torch.arange(csr.shape[0], device="cuda"), csr.indptr[1:] - csr.indptr[:-1])
+    sel = torch.from_numpy(gid >= 0).cuda()[rows]
+    colsum = torch.zeros(csr.shape[1], dtype=torch.float64, device="cuda").index_add_(0, csr.indices[sel].long(), csr.data[sel].double())
+    np.testing.assert_array_equal(sumx.sum(axis=0), colsum.cpu().numpy().astype(np.uint64))
+    # unit weights: S1 == sum x, S2 >= S1 with equality iff every count is 1, S3 == S1
+    S1u, _, _ = blocks.moments(np.ones(csr.shape[0]))
+    np.testing.assert_array_equal(S1u[0], sumx.astype(np.float64))
+    np.testing.assert_array_equal(S1u[2], sumx.astype(np.float64))
+    assert (S1u[1] >= S1u[0]).all() and ((S1u[1] == S1u[0]) == (maxx <= 1)).all()
+
+
+def test_histograms_and_multinomial_invariants(big):
+    engine, torch, csr, gid, blocks, sf = big
+    S, sumx, maxx = blocks.moments(1.0 / sf)
+    rng = np.random.default_rng(9)
+    genes = np.sort(rng.choice(np.flatnonzero(sumx.sum(axis=0) > 2000), size=300, replace=False))
+    n_bins = 31
+    sf_bin = rng.integers(0, n_bins, size=csr.shape[0]).astype(np.uint8)
+    sf_table = np.linspace(0.4, 2.5, n_bins)
+    B = 64
+    bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(8, 0.07), B)
+    Nc = blocks.grp_ncells
+    for p in rng.choice(bs.n_pairs, size=40, replace=False):
+        bi, xi, mu = bs.bins_of_pair(int(p))
+        g = int(p % 8)
+        assert mu.sum() == Nc[g]                                           # bins partition the group's cells
+        assert (mu[xi > 0] * xi[xi > 0]).sum() == sumx[g, genes[p // 8]]   # and carry the gene's total count
+        assert xi.max() == maxx[g, genes[p // 8]]
+    r = rng.random((2, bs.n_pairs))
+    zeros = np.zeros(bs.n_pairs)
+    bs.alloc_outputs(zeros, zeros)
+    bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
+    w = bs.w_dump                                                          # [slot][k][B] int32 on device
+    tot = w.sum(dim=1).cpu().numpy()                                       # multinomial weights of every replicate sum to N_g
+    act = np.flatnonzero(bs.slot_pair >= 0)
+    want = Nc[bs.slot_pair[act] % 8]
+    assert (tot[act] == want[:, None]).all()
+    assert (w >= 0).all().item()
+    # replicate means are non-negative and finite; bootstrap mean of the replicate means is close to the estimate
+    rm = engine.host(bs.raw_mean)[:, 1:]
+    assert np.isfinite(rm[bs.active]).all() and (rm[bs.active] >= 0).all()
