@@ -176,6 +176,20 @@ int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_
                       const int32_t *d_test_gene, const double *d_W /* [n_tests][n_groups] */, const uint8_t *d_good /* [n_genes][n_groups] */,
                       int64_t n_tests, int32_t which, double *d_coef, double *d_stats, void *stream);
 
+/* ---- resample_rep=True: hierarchical resampling of replicate groups ------------------------------------
+ * replaces hypothesis_test._regress_1d :273-286 and _cross_coef_resampled :231-239.
+ * mm_residualize: in place y~ = M y on the [n_genes*n_groups][ld] rows (columns 0..n_cols-1); gene g uses the
+ * n_groups x n_groups matrix d_M[d_gene_mask[g]] (zero rows/columns on invalid groups -> NaN rows). */
+int mm_residualize(double *d_y, int64_t ld, int32_t n_cols, int32_t n_groups, int32_t n_genes, const int32_t *d_gene_mask,
+                   const double *d_M, void *stream);
+/* mm_cross_resampled: coefficient of resampled column c < num_boot (column 0 = observed).  d_tt[test][group] =
+ * residualised treatment; d_rep/d_bcol [gene][n_groups][num_boot] = group index (into the gene's valid groups) and
+ * replicate column drawn for row i of column c (np.random.choice replay), or both NULL to draw them on the device.
+ * d_status |= 1 if a gathered value is not finite (the reference would have dropped that replicate column). */
+int mm_cross_resampled(const double *d_yt, int64_t ld, int32_t num_boot, int32_t n_groups, const int32_t *d_test_gene,
+                       const double *d_tt, const uint8_t *d_good, const double *d_Nc, const int16_t *d_rep, const int32_t *d_bcol,
+                       uint64_t seed, int64_t n_tests, double *d_coef, double *d_stats, int32_t *d_status, void *stream);
+
 /* ==== 2D (gene pairs) ===========================================================================
  * K11 step 1: copy the columns of the n_cols genes with d_col_id[gene] = m >= 0 out of the SELL blocks into a
  * gene-contiguous store: entries of (block b, column m) at d_out[col_ptr[b*(n_cols+1)+m] .. col_ptr[b*(n_cols+1)+m+1])

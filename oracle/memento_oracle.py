@@ -252,14 +252,50 @@ def compute_asl(perm_diff, resampling="bootstrap", approx=False):
             return fallback
 
 
-def regress_1d(cov, trt, boot_mean, boot_var, Nc, resampling="bootstrap", approx=False):
-    """_regress_1d without resample_rep (hypothesis_test.py:242-300)."""
+def cross_coef_resampled(A, B, w, drop_degenerate=False):
+    """Per-column weighted slope with per-column rows/weights (hypothesis_test.py:231-239).
+    A: (n, nb, T) residualised treatment of the drawn groups, B: (n, nb), w: (n, nb).
+    ``drop_degenerate``: NaN for columns whose drawn groups all share one treatment value -- there the reference's
+    value is 0/0 or a ratio of round-off residues (noise); the HIP kernel always reports NaN for them."""
+    Bc = B - np.average(B, axis=0, weights=w)
+    Ac = A - (A * w[:, :, None]).sum(axis=0) / w.sum(axis=0)[:, None]
+    ss = (Ac ** 2 * w[:, :, None]).sum(axis=0) / w.sum(axis=0)[:, None]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out = np.einsum("ijk,ij->jk", Ac * w[:, :, None], Bc).T / w.sum(axis=0) / ss.T
+    if drop_degenerate:
+        out[(ss <= 1e-24 * np.abs(A).max(axis=0) ** 2).T] = np.nan
+    return out
+
+
+def _sklearn_like_residualize(Z, cov, w):
+    """Z - LinearRegression().fit(cov, Z, w).predict(cov), following sklearn's own steps (weighted centring, min-norm
+    lstsq on the sqrt-weighted centred design) so equal inputs give bit-identical residuals."""
+    c_off, z_off = np.average(cov, axis=0, weights=w), np.average(Z, axis=0, weights=w)
+    sw = np.sqrt(w)[:, None]
+    coef, *_ = np.linalg.lstsq((cov - c_off) * sw, (Z - z_off) * sw, rcond=None)
+    return Z - (cov @ coef + (z_off - c_off @ coef))
+
+
+def regress_1d(cov, trt, boot_mean, boot_var, Nc, resampling="bootstrap", approx=False, resample_rep=False,
+               drop_degenerate=False):
+    """_regress_1d (hypothesis_test.py:242-300); ``resample_rep`` draws from the global np.random stream like the
+    reference (:273-286)."""
     ok = np.all(np.isfinite(boot_mean), axis=0) & np.all(np.isfinite(boot_var), axis=0)
     bm, bv = boot_mean[:, ok], boot_var[:, ok]
     Nc = np.asarray(Nc, dtype=np.float64)
     if (trt == 1).mean() == 1:
         mc = np.average(bm, axis=0, weights=Nc).reshape(1, -1)
         vc = np.average(bv, axis=0, weights=Nc).reshape(1, -1)
+    elif resample_rep:
+        n, nb = bm.shape[0], bm.shape[1] - 1
+        bmt, bvt = _sklearn_like_residualize(bm, cov, Nc), _sklearn_like_residualize(bv, cov, Nc)
+        tt = _sklearn_like_residualize(trt, cov, Nc)
+        ra = np.random.choice(n, size=(n, nb))
+        ra[:, 0] = np.arange(n)
+        ba = np.random.choice(nb, (n, nb)) + 1
+        ba[:, 0] = 0
+        mc = cross_coef_resampled(tt[ra], bmt[(ra, ba)], Nc[ra], drop_degenerate)
+        vc = cross_coef_resampled(tt[ra], bvt[(ra, ba)], Nc[ra], drop_degenerate)
     else:
         tt = _weighted_residualize(trt, cov, Nc)
         mc = cross_coef(tt, _weighted_residualize(bm, cov, Nc), Nc)

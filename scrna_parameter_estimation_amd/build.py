@@ -18,7 +18,7 @@ SOURCES = [
     ("moments.hip", []),
     ("hist.hip", ["-ffp-contract=off"]),
     ("boot.hip", ["-ffp-contract=off"]),
-    ("contract.hip", []),
+    ("contract.hip", ["-ffp-contract=off"]),   # mirrors numpy's unfused weighted sums (degenerate resampled columns)
     ("pairs.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
@@ -44,6 +44,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "memento_hip.h"))
+    headers.append(os.path.abspath(__file__))  # flag changes in this file rebuild everything
     objs, jobs = [], []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)

@@ -129,6 +129,179 @@ __global__ __launch_bounds__(K9_THREADS) void k_contract_stats(const double *__r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// resample_rep=True (hypothesis_test.py:273-286, :231-239): hierarchical resampling of the replicate groups.
+// Step 1: residualise the rows of a gene on the covariates, y~ = M y  (M = I - H of the weighted fit, zero on bad
+// groups), column by column (one thread owns a column, so it can run in place on a scratch copy).
+__global__ __launch_bounds__(256) void k_residualize(double *__restrict__ y, int64_t ld, int32_t n_cols, int32_t n_groups,
+                                                     const int32_t *__restrict__ gene_mask /* [n_genes] index into M */,
+                                                     const double *__restrict__ M /* [n_masks][ng][ng] */) {
+  extern __shared__ double sm[];
+  int gene = blockIdx.y;
+  const double *Mg = M + (int64_t)gene_mask[gene] * n_groups * n_groups;
+  for (int i = threadIdx.x; i < n_groups * n_groups; i += blockDim.x) sm[i] = Mg[i];
+  __syncthreads();
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  double *base = y + (int64_t)gene * n_groups * ld + c;
+  double in[64], out[64];
+  if (n_groups > 64) return;
+  for (int j = 0; j < n_groups; j++) in[j] = base[(int64_t)j * ld];
+  for (int i = 0; i < n_groups; i++) {
+    double acc = 0.0;
+    bool any = false;
+    for (int j = 0; j < n_groups; j++) {
+      double m = sm[i * n_groups + j];
+      if (m != 0.0) {
+        acc += m * in[j];
+        any = true;
+      }
+    }
+    out[i] = any ? acc : NAN;
+  }
+  for (int i = 0; i < n_groups; i++) base[(int64_t)i * ld] = out[i];
+}
+
+__device__ __forceinline__ uint64_t rr_mix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// Step 2: per test and resampled column c < num_boot: rows i = 0..n-1 take group rep[i][c] and replicate column
+// bcol[i][c] of the residualised response; coefficient = weighted slope on the residualised treatment of the drawn
+// groups (_cross_coef_resampled).  rep/bcol NULL -> drawn on the fly from a counter-based RNG (column 0 is always the
+// identity / observed column).  Then the same null statistics as k_contract_stats.
+__global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__restrict__ yt, int64_t ld, int32_t num_boot,
+                                                                int32_t n_groups, const int32_t *__restrict__ test_gene,
+                                                                const double *__restrict__ tt /* [n_tests][ng] residualised treatment */,
+                                                                const uint8_t *__restrict__ good, const double *__restrict__ Nc,
+                                                                const int16_t *__restrict__ rep, const int32_t *__restrict__ bcol,
+                                                                uint64_t seed, double *__restrict__ coef, double *__restrict__ stats,
+                                                                int32_t *__restrict__ status) {
+  extern __shared__ double sm[];
+  double *tts = sm;                               // [ng]
+  double *ncs = sm + n_groups;                    // [ng]
+  int32_t *glist = (int32_t *)(sm + 2 * n_groups);
+  __shared__ double red[K9_THREADS / 64];
+  __shared__ int n_good_s;
+  int64_t t = blockIdx.x;
+  int gene = test_gene[t];
+  const uint8_t *gd = good + (int64_t)gene * n_groups;
+  if (threadIdx.x == 0) {
+    int ng = 0;
+    for (int j = 0; j < n_groups; j++)
+      if (gd[j]) glist[ng++] = j;
+    n_good_s = ng;
+  }
+  for (int j = threadIdx.x; j < n_groups; j += K9_THREADS) {
+    tts[j] = tt[t * n_groups + j];
+    ncs[j] = Nc[j];
+  }
+  __syncthreads();
+  int n = n_good_s;
+  double *crow = coef + t * ld;
+  double *st = stats + t * 8;
+  int64_t row_base = (int64_t)gene * n_groups;
+  if (n == 0) {
+    for (int c = threadIdx.x; c <= num_boot; c += K9_THREADS) crow[c] = NAN;
+    if (threadIdx.x == 0) {
+      st[0] = NAN; st[1] = NAN; st[2] = 0; st[3] = 0; st[4] = NAN; st[5] = 0; st[6] = NAN; st[7] = NAN;
+    }
+    return;
+  }
+  const int16_t *rg = rep ? rep + (int64_t)gene * n_groups * num_boot : nullptr;
+  const int32_t *bg = bcol ? bcol + (int64_t)gene * n_groups * num_boot : nullptr;
+  double s_sum = 0.0, s_cnt = 0.0, s_min = INFINITY, s_max = -INFINITY;
+  bool bad = false;
+  for (int c = threadIdx.x; c < num_boot; c += K9_THREADS) {
+    double sw = 0.0, swy = 0.0, swa = 0.0, amax = 0.0;
+    // first pass: weighted means
+    for (int i = 0; i < n; i++) {
+      int r, bb;
+      if (c == 0) { r = i; bb = 0; }
+      else if (rg) { r = rg[(int64_t)i * num_boot + c]; bb = bg[(int64_t)i * num_boot + c]; }
+      else {
+        uint64_t h = rr_mix(seed ^ rr_mix(((uint64_t)gene << 32) ^ ((uint64_t)i << 24) ^ (uint64_t)c));
+        r = (int)(h % (uint64_t)n);
+        bb = (int)(rr_mix(h) % (uint64_t)num_boot) + 1;
+      }
+      int j = glist[r];
+      double y = yt[(row_base + j) * ld + bb];
+      double w = ncs[j];
+      if (!isfinite(y)) bad = true;
+      sw += w; swy += w * y; swa += w * tts[j];
+      amax = fmax(amax, fabs(tts[j]));
+    }
+    double mB = swy / sw, mA = swa / sw;
+    double ss = 0.0, num = 0.0;
+    for (int i = 0; i < n; i++) {
+      int r, bb;
+      if (c == 0) { r = i; bb = 0; }
+      else if (rg) { r = rg[(int64_t)i * num_boot + c]; bb = bg[(int64_t)i * num_boot + c]; }
+      else {
+        uint64_t h = rr_mix(seed ^ rr_mix(((uint64_t)gene << 32) ^ ((uint64_t)i << 24) ^ (uint64_t)c));
+        r = (int)(h % (uint64_t)n);
+        bb = (int)(rr_mix(h) % (uint64_t)num_boot) + 1;
+      }
+      int j = glist[r];
+      double y = yt[(row_base + j) * ld + bb];
+      double w = ncs[j], da = tts[j] - mA;
+      ss += da * da * w;
+      num += (da * w) * (y - mB);
+    }
+    // Degenerate column: every drawn group has the same (residualised) treatment, so the slope is 0/0.  The reference
+    // gets NaN there when its weighted mean happens to round to exactly that value and O(1) rounding noise otherwise
+    // (hypothesis_test.py:234-239 -- a ratio of two round-off residues); here such a column is always NaN, which
+    // np.nanstd and the isfinite filter of _compute_asl ignore.
+    double val = num / sw / (ss / sw);
+    if (ss / sw <= 1e-24 * amax * amax) val = NAN;
+    crow[c] = val;
+    if (val == val) {
+      s_min = fmin(s_min, val);
+      s_max = fmax(s_max, val);
+      if (c > 0) {
+        s_sum += val;
+        s_cnt += 1.0;
+      }
+    }
+  }
+  if (threadIdx.x == 0) crow[num_boot] = NAN;  // the row has ld = num_boot + 1 slots; the resampled row uses num_boot
+  if (bad) atomicOr(status, 1);
+  double tot = wg_sum(s_sum, red);
+  double cnt = wg_sum(s_cnt, red);
+  double mn = wg_min(s_min, red);
+  double mx = wg_max(s_max, red);
+  __threadfence_block();
+  __syncthreads();
+  double c0 = crow[0];
+  double mean1 = cnt > 0 ? tot / cnt : NAN;
+  double a0 = fabs(c0);
+  double s_sq = 0.0, s_ext = 0.0;
+  for (int c = 1 + threadIdx.x; c < num_boot; c += K9_THREADS) {
+    double val = crow[c];
+    if (val == val) {
+      double d = val - mean1;
+      s_sq += d * d;
+      double nul = val - c0;
+      if (nul > a0 || nul < -a0) s_ext += 1.0;
+    }
+  }
+  double sq = wg_sum(s_sq, red);
+  double ext = wg_sum(s_ext, red);
+  if (threadIdx.x == 0) {
+    st[0] = c0;
+    st[1] = cnt > 0 ? sqrt(sq / cnt) : NAN;
+    st[2] = cnt;
+    st[3] = ext;
+    st[4] = mean1 - c0;
+    st[5] = (mn == mx) ? 1.0 : 0.0;
+    st[6] = mn;
+    st[7] = mx;
+  }
+}
+
 extern "C" {
 
 int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups,
@@ -140,6 +313,30 @@ int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_
   size_t shm = (size_t)n_groups * 12 + 8;
   hipLaunchKernelGGL(k_contract_stats, dim3((unsigned)n_tests), dim3(K9_THREADS), shm, (hipStream_t)stream, d_ym, d_yv, ld, num_boot,
                      n_groups, d_test_gene, d_W, d_good, which, d_coef, d_stats);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_residualize(double *d_y, int64_t ld, int32_t n_cols, int32_t n_groups, int32_t n_genes, const int32_t *d_gene_mask,
+                   const double *d_M, void *stream) {
+  MM_ARG(d_y && d_gene_mask && d_M && n_cols > 0 && n_groups > 0 && n_groups <= 64 && n_genes >= 0 && n_genes <= 65535);
+  if (n_genes == 0) return MM_OK;
+  size_t shm = (size_t)n_groups * n_groups * 8;
+  hipLaunchKernelGGL(k_residualize, dim3((unsigned)((n_cols + 255) / 256), (unsigned)n_genes), dim3(256), shm, (hipStream_t)stream, d_y,
+                     ld, n_cols, n_groups, d_gene_mask, d_M);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_cross_resampled(const double *d_yt, int64_t ld, int32_t num_boot, int32_t n_groups, const int32_t *d_test_gene,
+                       const double *d_tt, const uint8_t *d_good, const double *d_Nc, const int16_t *d_rep, const int32_t *d_bcol,
+                       uint64_t seed, int64_t n_tests, double *d_coef, double *d_stats, int32_t *d_status, void *stream) {
+  MM_ARG(d_yt && d_test_gene && d_tt && d_good && d_Nc && d_coef && d_stats && d_status);
+  MM_ARG(n_tests >= 0 && n_groups > 0 && num_boot > 1 && ld >= (int64_t)num_boot + 1 && ((d_rep == nullptr) == (d_bcol == nullptr)));
+  if (n_tests == 0) return MM_OK;
+  size_t shm = (size_t)n_groups * 20 + 8;
+  hipLaunchKernelGGL(k_cross_resampled, dim3((unsigned)n_tests), dim3(K9_THREADS), shm, (hipStream_t)stream, d_yt, ld, num_boot, n_groups,
+                     d_test_gene, d_tt, d_good, d_Nc, d_rep, d_bcol, seed, d_coef, d_stats, d_status);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -410,6 +410,30 @@ class Bootstrap1D:
         return coef, host(stats)[:n_tests]
 
 
+    def contract_resampled(self, test_gene, tt, good, which, gene_mask, M, Nc, rep=None, bcol=None, seed=0):
+        """resample_rep=True: residualise the response rows (copy), then the resampled weighted slopes + null statistics.
+        ``rep``/``bcol`` [n_genes][n_groups][B] (int16/int32) replay np.random.choice; None -> drawn on the device."""
+        torch = _torch()
+        s = _stream()
+        n_tests = len(test_gene)
+        src = self.yv if which else self.ym
+        yt = src.clone()
+        d_gm, d_M = dev(np.asarray(gene_mask, dtype=np.int32)), dev(np.asarray(M, dtype=np.float64))
+        _lib.call("mm_residualize", P(yt), self.ld, self.ld, self.ng, self.n_tested, P(d_gm), P(d_M), s)
+        coef = empty((max(1, n_tests), self.ld), torch.float64)
+        stats = empty((max(1, n_tests), 8), torch.float64)
+        status = zeros((1,), torch.int32)
+        d_tg, d_tt, d_good = dev(np.asarray(test_gene, dtype=np.int32)), dev(np.asarray(tt, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
+        d_nc = dev(np.asarray(Nc, dtype=np.float64))
+        d_rep = dev(np.asarray(rep, dtype=np.int16)) if rep is not None else None
+        d_bcol = dev(np.asarray(bcol, dtype=np.int32)) if bcol is not None else None
+        _lib.call("mm_cross_resampled", P(yt), self.ld, self.B, self.ng, P(d_tg), P(d_tt), P(d_good), P(d_nc), P(d_rep), P(d_bcol),
+                  int(seed) & ((1 << 64) - 1), n_tests, P(coef), P(stats), P(status), s)
+        if int(status.item()) & 1:
+            raise NotImplementedError("resample_rep=True with non-finite replicate columns (the reference would drop them)")
+        return coef, host(stats)[:n_tests]
+
+
 # =================================================================================================
 # 2D: gene pairs
 # =================================================================================================

@@ -45,3 +45,36 @@ def weight_rows(cov, trt, Nc, good):
         Wg = ((Ac * wbar[:, None]).T @ center @ M) / ss[:, None]
     W[:, idx] = Wg
     return W
+
+
+def residual_parts(cov, trt, Nc, good):
+    """For resample_rep=True (hypothesis_test.py:269-286): the residual maker M = I - H of the weighted fit on
+    [1, cov] embedded in an n_groups x n_groups matrix (zero rows/columns on groups that are not ``good``), and
+    the residualised treatment (T x n_groups, zero on bad groups)."""
+    cov = np.asarray(cov, dtype=np.float64)
+    trt = np.asarray(trt, dtype=np.float64)
+    Nc = np.asarray(Nc, dtype=np.float64)
+    good = np.asarray(good, dtype=bool)
+    idx = np.flatnonzero(good)
+    n = len(idx)
+    ng = len(good)
+    M = np.zeros((ng, ng))
+    tt = np.zeros((trt.shape[1], ng))
+    if n == 0:
+        return M, tt
+    Xa = np.column_stack([np.ones(n), cov[idx]])
+    w = Nc[idx]
+    sw = np.sqrt(w)
+    H = Xa @ (np.linalg.pinv(Xa * sw[:, None]) * sw[None, :])
+    Mg = np.eye(n) - H
+    M[np.ix_(idx, idx)] = Mg
+    # The residualised TREATMENT follows sklearn's own arithmetic (centre by the weighted means, min-norm lstsq on the
+    # sqrt-weighted centred design, intercept from the offsets): groups with equal treatment then get bit-identical
+    # residuals, which the degenerate resampled columns (every drawn group has the same treatment -> 0/0 -> NaN,
+    # ignored by nanstd) rely on.
+    c, t = cov[idx], trt[idx]
+    c_off, t_off = np.average(c, axis=0, weights=w), np.average(t, axis=0, weights=w)
+    coef, *_ = np.linalg.lstsq((c - c_off) * sw[:, None], (t - t_off) * sw[:, None], rcond=None)
+    pred = c @ coef + (t_off - c_off @ coef)
+    tt[:, idx] = (t - pred).T
+    return M, tt

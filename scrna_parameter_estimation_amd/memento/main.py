@@ -331,8 +331,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
     if kwargs['resampling'] != 'bootstrap':
         raise NotImplementedError("only resampling='bootstrap' is implemented on the HIP path")
-    if kwargs.get('resample_rep', False):
-        raise NotImplementedError("resample_rep=True is not implemented on the HIP path yet")
+    resample_rep = bool(kwargs.get('resample_rep', False))
     if rng not in ('replay', 'fast'):
         raise ValueError("rng must be 'replay' or 'fast'")
     if strict and rng != 'replay':
@@ -368,35 +367,87 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     r1, r0 = np.zeros(n_pairs), np.zeros(n_pairs)
     live = np.flatnonzero(~skip)
 
-    def draw_hash(first):
-        idx = live[live >= first]
-        u = np.random.random(2 * len(idx))          # same stream positions as random(1) then random() per pair
-        r1[idx], r0[idx] = u[0::2], u[1::2]
+    pair_gene = np.arange(n_pairs) // ng
+    known_bad = np.zeros(n_pairs, dtype=bool)       # pairs whose fill found no valid replicate (strict mode bookkeeping)
+    rep_assign = bcol_assign = None
+    if resample_rep and strict:
+        rep_assign = np.zeros((G, ng, num_boot), dtype=np.int16)
+        bcol_assign = np.zeros((G, ng, num_boot), dtype=np.int32)
+
+    def gene_uses_resampling(gi, n_good):
+        if not resample_rep or n_good == 0:
+            return False
+        cols = None if treatment_for_gene is None else [trt_cols.index(c) for c in treatment_for_gene[names[gi]]]
+        t = trt_all if cols is None else trt_all[:, cols]
+        gmask = ((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng]
+        return not (t[gmask] == 1).mean() == 1                                                   # hypothesis_test.py:262
+
+    def draw_assignments(gi):
+        n = int(((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng].sum())
+        if gene_uses_resampling(gi, n):
+            ra = np.random.choice(n, size=(n, num_boot))
+            ra[:, 0] = np.arange(n)
+            ba = np.random.choice(num_boot, (n, num_boot)) + 1
+            ba[:, 0] = 0
+            rep_assign[gi, :n], bcol_assign[gi, :n] = ra, ba
+
+    def draw_stream(first, stop_pair=None, pending=None):
+        """Consume the global np.random stream exactly as the reference does from pair ``first`` on: per gene the two
+        hash uniforms of every live group (bootstrap.py:62,65) and -- with resample_rep -- the two np.random.choice
+        draws of _regress_1d (hypothesis_test.py:275-278) after the gene's last group.  ``pending``: a gene whose
+        groups are all done but whose choice draws are still due; ``stop_pair``: stop right after that pair's hash."""
+        if not (resample_rep and strict):
+            idx = live[live >= first] if stop_pair is None else live[(live >= first) & (live <= stop_pair)]
+            u = np.random.random(2 * len(idx))      # same stream positions as random(1) then random() per pair
+            r1[idx], r0[idx] = u[0::2], u[1::2]
+            return
+        if pending is not None:
+            draw_assignments(pending)
+        for gi in range(int(first // ng), G):
+            lo_p = max(first, gi * ng)
+            hi_p = (gi + 1) * ng - 1 if stop_pair is None else min((gi + 1) * ng - 1, stop_pair)
+            idx = live[(live >= lo_p) & (live <= hi_p)]
+            u = np.random.random(2 * len(idx))
+            r1[idx], r0[idx] = u[0::2], u[1::2]
+            if stop_pair is not None and stop_pair < (gi + 1) * ng:
+                return
+            draw_assignments(gi)
 
     if not strict:
-        draw_hash(0)
+        draw_stream(0)
         n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
         bad_fill = (n_inv < 0).any(axis=1)
     else:
         n_inv_all = np.zeros((n_pairs, 2), dtype=np.int32)
-        first = 0
+        first, pending = 0, None
         while first < n_pairs:
             saved = np.random.get_state()
-            draw_hash(first)
+            draw_stream(first, pending=pending)
+            after = np.random.get_state()
             n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first, mean_only=mean_only)
             n_inv_all[first:] = n_inv
-            needs = np.flatnonzero((~skip[first:]) & ((n_inv > 0).any(axis=1))) + first
+            event = (n_inv > 0).any(axis=1)
+            if resample_rep:
+                event |= (n_inv < 0).any(axis=1) & ~known_bad[first:]      # a group without valid replicates shrinks num_rep
+            needs = np.flatnonzero((~skip[first:]) & event) + first
             if len(needs) == 0:
+                np.random.set_state(after)
+                pending = None
                 break
             p = int(needs[0])
             np.random.set_state(saved)
-            np.random.random(2 * int((live >= first).sum() - (live > p).sum()))   # hash draws of pairs first..p
+            draw_stream(first, stop_pair=p, pending=pending)                # everything the reference drew up to pair p's hash
             for t, col in ((bs.ym, 0), (bs.yv, 1)):
                 if n_inv_all[p, col] > 0:
                     row = engine.host(t[p, 1:])
                     t[p, 1:] = engine.dev(_host_fill(row))
                     n_inv_all[p, col] = 0
+            if (n_inv_all[p] < 0).any():
+                known_bad[p] = True
+            pending = p // ng if (resample_rep and p % ng == ng - 1) else None
             first = p + 1
+        if pending is not None:
+            draw_assignments(pending)
         bad_fill = (n_inv_all < 0).any(axis=1)
 
     active_all = (~skip) & (bs.K >= 2)                       # bootstrap.py:97-98: a single bin gives NaN replicates
@@ -425,8 +476,37 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     n_tests = len(test_gene)
     Wmat = np.concatenate(test_rows, axis=0) if test_rows else np.zeros((0, ng))
     out = {}
+    use_rr = resample_rep and n_tests > 0
+    if use_rr:
+        # residual maker / residualised treatment per valid-group mask; tests whose treatment is all ones keep the
+        # weighted-average branch (hypothesis_test.py:262-265) and are not resampled
+        masks, gene_mask, tt_rows, rr_test = {}, np.zeros(G, dtype=np.int32), [], np.zeros(n_tests, dtype=bool)
+        Ms = []
+        ti = 0
+        for gi in range(G):
+            cols = None if treatment_for_gene is None else [trt_cols.index(c) for c in treatment_for_gene[names[gi]]]
+            t = trt_all if cols is None else trt_all[:, cols]
+            key = (good[gi].tobytes(), None if cols is None else tuple(cols))
+            if key not in masks:
+                Mg, ttg = _design.residual_parts(cov, t, Nc_list, good[gi])
+                masks[key] = (len(Ms), ttg)
+                Ms.append(Mg)
+            gene_mask[gi], ttg = masks[key]
+            nt = t.shape[1]
+            allones = good[gi].any() and (t[good[gi]] == 1).mean() == 1
+            tt_rows.append(ttg)
+            rr_test[ti:ti + nt] = not allones
+            ti += nt
+        tt_mat = np.concatenate(tt_rows, axis=0)
+        Mstack = np.stack(Ms)
     for which, tag in ((0, 'mean'), (1, 'var')):
         coef, stt = bs.contract(test_gene, Wmat, good, which)                                         # K9+K10
+        if use_rr and rr_test.any():
+            coef_r, stt_r = bs.contract_resampled(test_gene, tt_mat, good, which, gene_mask, Mstack, Nc_list,
+                                                  rep_assign, bcol_assign, seed=fill_seed + 17)
+            stt = np.where(rr_test[:, None], stt_r, stt)
+            rr_idx = engine.dev(np.flatnonzero(rr_test))
+            coef[rr_idx] = coef_r[rr_idx]
         no_group = ~good[np.asarray(test_gene, dtype=np.int64)].any(axis=1) if n_tests else np.zeros(0, bool)
         c0, se = stt[:, 0].copy(), stt[:, 1].copy()
         p = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
@@ -440,6 +520,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     for k in ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl'):
         m['1d_ht'][k] = out[k]
     st.last_bootstrap = bs
+    st.last_assignments = (rep_assign, bcol_assign)
     if not inplace:
         return adata
 

@@ -104,6 +104,13 @@ def api_case(name, n_cells, n_genes, density, n_cond, n_rep, seed, num_boot, ht_
     ht = m["1d_ht"]
     for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
         out["ht_" + k] = np.asarray(ht[k]).copy()
+    if two_d_pairs:   # (api_small only) hierarchical resampling of the replicate groups, hypothesis_test.py:273-286
+        trt2 = trt.copy()
+        np.random.seed(ht_seed + 2)
+        memento.ht_1d_moments(adata, covariate=cov, treatment=trt2, num_boot=num_boot, num_cpus=1, verbose=0,
+                              resampling="bootstrap", approx=approx, resample_rep=True)
+        for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+            out["htrr_" + k] = np.asarray(m["1d_ht"][k]).copy()
     out["ht_seed"] = np.int64(ht_seed)
     out["num_boot"] = np.int64(num_boot)
     out["approx"] = np.bool_(approx)

@@ -106,6 +106,42 @@ def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     assert np.median(np.abs(ht["var_se"][ok] / g["ht_var_se"][ok] - 1)) < 0.15
 
 
+def test_ht_1d_resample_rep(api_small):
+    """resample_rep=True (hierarchical resampling of the replicate groups, hypothesis_test.py:273-286), strict replay
+    of the np.random.choice draws.  Columns whose drawn groups all share one treatment are 0/0: the reference reports
+    NaN or O(1) round-off noise for them depending on rounding; the kernel always reports NaN.  So: observed
+    coefficients match the real reference exactly, everything matches the oracle run with ``drop_degenerate`` (same
+    stream), and the reference's SEs -- which include that noise -- agree within a few percent."""
+    from conftest import golden_inputs
+    from oracle import memento_oracle as orc
+
+    g = api_small
+    memento, adata = _run_to_moments(g)
+    cov, trt = _design(memento, adata, g)
+    np.random.seed(int(g["ht_seed"]) + 2)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=False, resample_rep=True, strict=True)
+    ht = {k: v.copy() for k, v in adata.uns["memento"]["1d_ht"].items() if k.endswith(("coef", "se", "asl"))}
+    np.testing.assert_allclose(ht["mean_coef"], g["htrr_mean_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(ht["var_coef"], g["htrr_var_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
+    ok = np.isfinite(g["htrr_mean_se"])
+    assert np.percentile(np.abs(ht["mean_se"][ok] / g["htrr_mean_se"][ok] - 1), 90) < 0.12
+    X, gid, ng, q = golden_inputs(g)
+    mom = dict(mean=g["mean"], res_var=g["res_var"], mv_fit=g["mv_regressor"])
+    np.random.seed(int(g["ht_seed"]) + 2)
+    want = orc.ht_1d(X[:, g["overall_gene_filter"]], gid, ng, g["approx_sf"], mom, g["covariate"], g["treatment"],
+                     int(g["num_boot"]), g["group_q"], resampling="bootstrap", approx=False, resample_rep=True, drop_degenerate=True)
+    for k, w in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], want):
+        np.testing.assert_allclose(ht[k], w, rtol=1e-5 if k.endswith("asl") else 1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+    # device-drawn assignments: same observed coefficients, SEs within Monte-Carlo error
+    np.random.seed(int(g["ht_seed"]) + 2)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=True, resample_rep=True)
+    ht2 = adata.uns["memento"]["1d_ht"]
+    np.testing.assert_allclose(ht2["mean_coef"], g["htrr_mean_coef"], rtol=1e-8, equal_nan=True)
+    assert np.median(np.abs(ht2["mean_se"][ok] / g["htrr_mean_se"][ok] - 1)) < 0.15
+
+
 def test_ht_1d_fast_rng_statistically_equivalent(api_small):
     """rng='fast': own RNG streams, replicate-parallel kernel.  Observed coefficients are RNG-independent (exact);
     standard errors agree with the reference's within Monte-Carlo error; p-values are strongly concordant."""

@@ -124,3 +124,16 @@ def test_2d(api_small):
     np.testing.assert_allclose(coef, g["ht2_corr_coef"], rtol=1e-7, equal_nan=True)
     np.testing.assert_allclose(se, g["ht2_corr_se"], rtol=1e-7, equal_nan=True)
     np.testing.assert_allclose(asl, g["ht2_corr_asl"], rtol=1e-7, equal_nan=True)
+
+
+def test_ht_1d_resample_rep(api_small):
+    """resample_rep=True: the oracle replays the reference's np.random.choice draws (hypothesis_test.py:273-286)."""
+    g = api_small
+    X, gid, ng, q = golden_inputs(g)
+    keep = g["overall_gene_filter"]
+    mom = dict(mean=g["mean"], res_var=g["res_var"], mv_fit=g["mv_regressor"])
+    np.random.seed(int(g["ht_seed"]) + 2)
+    out = orc.ht_1d(X[:, keep], gid, ng, g["approx_sf"], mom, g["covariate"], g["treatment"], int(g["num_boot"]),
+                    g["group_q"], resampling="bootstrap", approx=False, resample_rep=True)
+    for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], out):
+        np.testing.assert_allclose(v, g["htrr_" + k], rtol=1e-7, equal_nan=True, err_msg=k)
