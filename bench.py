@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("MM_BENCH_CONFIG", "C3"), choices=list(CONFIGS))
-    ap.add_argument("--num-cpus", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--num-cpus", type=int, default=0, help="host processes for the tail fits (default: min(16, cores / ranks))")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -111,15 +111,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    if args.num_cpus <= 0:
+        args.num_cpus = max(1, min(16, (os.cpu_count() or 1) // world))
+    dev_idx = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_idx)
     comm = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # nccl (= RCCL over xGMI) in production; MM_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU
+        backend = os.environ.get("MM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_idx))
+        else:
+            dist.init_process_group(backend=backend)
         from scrna_parameter_estimation_amd.dist import Comm
 
-        comm = Comm(device="cuda")
+        comm = Comm(device="cuda" if backend == "nccl" else "cpu")
 
     from scrna_parameter_estimation_amd import AnnDataLite, engine, memento
     from scrna_parameter_estimation_amd import _lib
@@ -177,9 +185,10 @@ def main():
     barrier()
     elapsed = time.time() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        cdev = comm.device
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        nt = torch.tensor([float(n_tests)], dtype=torch.float64, device="cuda")
+        nt = torch.tensor([float(n_tests)], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(nt, op=torch.distributed.ReduceOp.SUM)
         elapsed, n_tests = float(tt.item()), float(nt.item())
 
