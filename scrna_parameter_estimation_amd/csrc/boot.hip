@@ -324,8 +324,8 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
   if (n_tiles == 0) return MM_OK;
   int64_t blocks = (n_tiles + 3) / 4;
   hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
-                     d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2], pcg_state[3],
-                     num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump);
+                     d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
+                     pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
