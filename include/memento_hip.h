@@ -217,7 +217,8 @@ int mm_pair_hist(const uint32_t *d_cols, const int64_t *d_col_ptr, int32_t n_col
 int mm_pair_bins_count(uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap_i, const int32_t *d_xcap_j,
                        const uint32_t *d_hist_i, const int64_t *d_hist_ptr, int64_t n_q, int32_t n_sf_bins, int32_t *d_K,
                        void *stream);
-/* replay order of the 2D bins: code = x_i*r1a + x_j*r1b + r0*approx_sf (bootstrap.py:62-65, two-column expr) */
+/* replay order of the 2D bins: code = x_i*r1a + x_j*r1b + r0*approx_sf (bootstrap.py:62-65, two-column expr);
+ * big = 0: K <= 1024, big = 1: K <= 4096 */
 int mm_bins_order2d(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap_i, const int32_t *d_xcap_j,
                     const int32_t *d_K, const int64_t *d_pair_list, int64_t n_list, int32_t big, int32_t n_groups, int32_t n_sf_bins,
                     const double *d_sf_table, const double *d_r1a, const double *d_r1b, const double *d_r0,

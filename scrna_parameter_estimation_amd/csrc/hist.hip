@@ -413,7 +413,7 @@ int mm_bins_order2d(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32
                        d_xcap_j, d_K, d_pair_list, n_list, n_groups, n_sf_bins, d_sf_table, d_r1a, d_r1b, d_r0, d_pair_slot, d_tile_ptr,
                        d_grp_ncells, d_pk, d_lq, d_v1, d_v2, d_a, d_b, d_status);
   } else {
-    constexpr int CAP = 8192, NT = 512;
+    constexpr int CAP = 4096, NT = 512;  // 20 B per bin: 80 KiB of LDS
     size_t shm = (size_t)CAP * 20;
     MM_HIP(hipFuncSetAttribute((const void *)k_bins_order2d<CAP, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL((k_bins_order2d<CAP, NT>), dim3((unsigned)n_list), dim3(NT), shm, (hipStream_t)stream, d_tab, d_tab_ptr, d_xcap_i,

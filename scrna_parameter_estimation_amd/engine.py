@@ -16,6 +16,7 @@ BLOCK_CELLS = 8192
 MAX_COUNT = (1 << 19) - 1
 ORDER_SMALL_CAP = 1024
 ORDER_BIG_CAP = 8192
+ORDER_BIG_CAP_2D = 4096
 # lane-packing cost model of the replay kernel (instructions per bin step: C0 + C1 * active lanes)
 PACK_C0 = float(__import__('os').environ.get('MM_PACK_C0', 250))
 PACK_C1 = float(__import__('os').environ.get('MM_PACK_C1', 14))
@@ -550,8 +551,8 @@ class Bootstrap2D:
         ng, B, ld = self.ng, self.B, self.ld
         active = (~np.asarray(skip, dtype=bool)) & (self.K >= 1)
         act = np.flatnonzero(active)
-        if len(act) and (self.K[act] > ORDER_BIG_CAP).any():
-            raise NotImplementedError(f"a (pair, group) has more than {ORDER_BIG_CAP} unique bins")
+        if len(act) and (self.K[act] > ORDER_BIG_CAP_2D).any():
+            raise NotImplementedError(f"a (pair, group) has more than {ORDER_BIG_CAP_2D} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         slot_of, n_tiles = pack_lanes(self.K[order], target_waves)
         pair_slot = np.full(self.n_q, -1, dtype=np.int64)

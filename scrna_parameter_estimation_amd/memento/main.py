@@ -314,7 +314,7 @@ def _host_fill(row):
 
 
 def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=1, num_cpus=1,
-                  rng='replay', strict=False, fill_seed=0, **kwargs):
+                  rng='replay', strict=False, fill_seed=0, max_rows=1 << 21, **kwargs):
     """Bootstrap hypothesis test of mean / residual-variance differences (reference: memento/main.py:341-415).
 
     ``rng='replay'``: the multinomial resampling replays numpy's ``Generator(PCG64(5))`` stream draw for
@@ -357,161 +357,173 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     if st.sf_bin is None:
         raise NotImplementedError("more than 255 size-factor bins")
 
-    bs = engine.Bootstrap1D(st.blocks, st.gene_idx, st.maxx, st.sf_bin, st.sf_table, gq, num_boot)   # K5
-    skip = _pair_skip(true_mean, true_rv)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        tm_log = np.where(skip, np.nan, np.log(true_mean.T.reshape(-1)))
-        tv_log = np.where(skip, np.nan, np.log(true_rv.T.reshape(-1)))
-    bs.alloc_outputs(tm_log, tv_log)
-    n_pairs = bs.n_pairs
-    r1, r0 = np.zeros(n_pairs), np.zeros(n_pairs)
-    live = np.flatnonzero(~skip)
+    def run_range(g0, g1):
+        """One chunk of genes [g0, g1): K5 histograms -> bootstrap -> contraction -> p-values."""
+        G = g1 - g0
+        bs = engine.Bootstrap1D(st.blocks, st.gene_idx[g0:g1], st.maxx, st.sf_bin, st.sf_table, gq, num_boot)   # K5
+        skip = _pair_skip(true_mean[:, g0:g1], true_rv[:, g0:g1])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            tm_log = np.where(skip, np.nan, np.log(true_mean[:, g0:g1].T.reshape(-1)))
+            tv_log = np.where(skip, np.nan, np.log(true_rv[:, g0:g1].T.reshape(-1)))
+        bs.alloc_outputs(tm_log, tv_log)
+        n_pairs = bs.n_pairs
+        r1, r0 = np.zeros(n_pairs), np.zeros(n_pairs)
+        live = np.flatnonzero(~skip)
 
-    pair_gene = np.arange(n_pairs) // ng
-    known_bad = np.zeros(n_pairs, dtype=bool)       # pairs whose fill found no valid replicate (strict mode bookkeeping)
-    rep_assign = bcol_assign = None
-    if resample_rep and strict:
-        rep_assign = np.zeros((G, ng, num_boot), dtype=np.int16)
-        bcol_assign = np.zeros((G, ng, num_boot), dtype=np.int32)
+        pair_gene = np.arange(n_pairs) // ng
+        known_bad = np.zeros(n_pairs, dtype=bool)       # pairs whose fill found no valid replicate (strict mode bookkeeping)
+        rep_assign = bcol_assign = None
+        if resample_rep and strict:
+            rep_assign = np.zeros((G, ng, num_boot), dtype=np.int16)
+            bcol_assign = np.zeros((G, ng, num_boot), dtype=np.int32)
 
-    def gene_uses_resampling(gi, n_good):
-        if not resample_rep or n_good == 0:
-            return False
-        cols = None if treatment_for_gene is None else [trt_cols.index(c) for c in treatment_for_gene[names[gi]]]
-        t = trt_all if cols is None else trt_all[:, cols]
-        gmask = ((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng]
-        return not (t[gmask] == 1).mean() == 1                                                   # hypothesis_test.py:262
+        def gene_uses_resampling(gi, n_good):
+            if not resample_rep or n_good == 0:
+                return False
+            cols = None if treatment_for_gene is None else [trt_cols.index(c) for c in treatment_for_gene[names[g0 + gi]]]
+            t = trt_all if cols is None else trt_all[:, cols]
+            gmask = ((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng]
+            return not (t[gmask] == 1).mean() == 1                                                   # hypothesis_test.py:262
 
-    def draw_assignments(gi):
-        n = int(((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng].sum())
-        if gene_uses_resampling(gi, n):
-            ra = np.random.choice(n, size=(n, num_boot))
-            ra[:, 0] = np.arange(n)
-            ba = np.random.choice(num_boot, (n, num_boot)) + 1
-            ba[:, 0] = 0
-            rep_assign[gi, :n], bcol_assign[gi, :n] = ra, ba
+        def draw_assignments(gi):
+            n = int(((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng].sum())
+            if gene_uses_resampling(gi, n):
+                ra = np.random.choice(n, size=(n, num_boot))
+                ra[:, 0] = np.arange(n)
+                ba = np.random.choice(num_boot, (n, num_boot)) + 1
+                ba[:, 0] = 0
+                rep_assign[gi, :n], bcol_assign[gi, :n] = ra, ba
 
-    def draw_stream(first, stop_pair=None, pending=None):
-        """Consume the global np.random stream exactly as the reference does from pair ``first`` on: per gene the two
-        hash uniforms of every live group (bootstrap.py:62,65) and -- with resample_rep -- the two np.random.choice
-        draws of _regress_1d (hypothesis_test.py:275-278) after the gene's last group.  ``pending``: a gene whose
-        groups are all done but whose choice draws are still due; ``stop_pair``: stop right after that pair's hash."""
-        if not (resample_rep and strict):
-            idx = live[live >= first] if stop_pair is None else live[(live >= first) & (live <= stop_pair)]
-            u = np.random.random(2 * len(idx))      # same stream positions as random(1) then random() per pair
-            r1[idx], r0[idx] = u[0::2], u[1::2]
-            return
-        if pending is not None:
-            draw_assignments(pending)
-        for gi in range(int(first // ng), G):
-            lo_p = max(first, gi * ng)
-            hi_p = (gi + 1) * ng - 1 if stop_pair is None else min((gi + 1) * ng - 1, stop_pair)
-            idx = live[(live >= lo_p) & (live <= hi_p)]
-            u = np.random.random(2 * len(idx))
-            r1[idx], r0[idx] = u[0::2], u[1::2]
-            if stop_pair is not None and stop_pair < (gi + 1) * ng:
+        def draw_stream(first, stop_pair=None, pending=None):
+            """Consume the global np.random stream exactly as the reference does from pair ``first`` on: per gene the two
+            hash uniforms of every live group (bootstrap.py:62,65) and -- with resample_rep -- the two np.random.choice
+            draws of _regress_1d (hypothesis_test.py:275-278) after the gene's last group.  ``pending``: a gene whose
+            groups are all done but whose choice draws are still due; ``stop_pair``: stop right after that pair's hash."""
+            if not (resample_rep and strict):
+                idx = live[live >= first] if stop_pair is None else live[(live >= first) & (live <= stop_pair)]
+                u = np.random.random(2 * len(idx))      # same stream positions as random(1) then random() per pair
+                r1[idx], r0[idx] = u[0::2], u[1::2]
                 return
-            draw_assignments(gi)
+            if pending is not None:
+                draw_assignments(pending)
+            for gi in range(int(first // ng), G):
+                lo_p = max(first, gi * ng)
+                hi_p = (gi + 1) * ng - 1 if stop_pair is None else min((gi + 1) * ng - 1, stop_pair)
+                idx = live[(live >= lo_p) & (live <= hi_p)]
+                u = np.random.random(2 * len(idx))
+                r1[idx], r0[idx] = u[0::2], u[1::2]
+                if stop_pair is not None and stop_pair < (gi + 1) * ng:
+                    return
+                draw_assignments(gi)
 
-    if not strict:
-        draw_stream(0)
-        n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
-        bad_fill = (n_inv < 0).any(axis=1)
-    else:
-        n_inv_all = np.zeros((n_pairs, 2), dtype=np.int32)
-        first, pending = 0, None
-        while first < n_pairs:
-            saved = np.random.get_state()
-            draw_stream(first, pending=pending)
-            after = np.random.get_state()
-            n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first, mean_only=mean_only)
-            n_inv_all[first:] = n_inv
-            event = (n_inv > 0).any(axis=1)
-            if resample_rep:
-                event |= (n_inv < 0).any(axis=1) & ~known_bad[first:]      # a group without valid replicates shrinks num_rep
-            needs = np.flatnonzero((~skip[first:]) & event) + first
-            if len(needs) == 0:
-                np.random.set_state(after)
-                pending = None
-                break
-            p = int(needs[0])
-            np.random.set_state(saved)
-            draw_stream(first, stop_pair=p, pending=pending)                # everything the reference drew up to pair p's hash
-            for t, col in ((bs.ym, 0), (bs.yv, 1)):
-                if n_inv_all[p, col] > 0:
-                    row = engine.host(t[p, 1:])
-                    t[p, 1:] = engine.dev(_host_fill(row))
-                    n_inv_all[p, col] = 0
-            if (n_inv_all[p] < 0).any():
-                known_bad[p] = True
-            pending = p // ng if (resample_rep and p % ng == ng - 1) else None
-            first = p + 1
-        if pending is not None:
-            draw_assignments(pending)
-        bad_fill = (n_inv_all < 0).any(axis=1)
-
-    active_all = (~skip) & (bs.K >= 2)                       # bootstrap.py:97-98: a single bin gives NaN replicates
-    good = (active_all & ~bad_fill).reshape(G, ng)           # hypothesis_test.py:193-200
-
-    # tests: gene-major x treatment column (main.py:399-404)
-    test_gene, test_rows = [], []
-    cache = {}
-    for gi in range(G):
-        if treatment_for_gene is None:
-            cols = None
-            nt = trt_all.shape[1]
+        if not strict:
+            draw_stream(0)
+            n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
+            bad_fill = (n_inv < 0).any(axis=1)
         else:
-            cols = [trt_cols.index(c) for c in treatment_for_gene[names[gi]]]
-            nt = len(cols)
-        key = (good[gi].tobytes(), None if cols is None else tuple(cols))
-        W = cache.get(key)
-        if W is None:
-            t = trt_all if cols is None else trt_all[:, cols]
-            W = _design.weight_rows(cov, t, Nc_list, good[gi])
-            if W.shape[0] != nt:
-                W = np.repeat(W[:1], nt, axis=0)
-            cache[key] = W
-        test_gene.extend([gi] * nt)
-        test_rows.append(W)
-    n_tests = len(test_gene)
-    Wmat = np.concatenate(test_rows, axis=0) if test_rows else np.zeros((0, ng))
-    out = {}
-    use_rr = resample_rep and n_tests > 0
-    if use_rr:
-        # residual maker / residualised treatment per valid-group mask; tests whose treatment is all ones keep the
-        # weighted-average branch (hypothesis_test.py:262-265) and are not resampled
-        masks, gene_mask, tt_rows, rr_test = {}, np.zeros(G, dtype=np.int32), [], np.zeros(n_tests, dtype=bool)
-        Ms = []
-        ti = 0
+            n_inv_all = np.zeros((n_pairs, 2), dtype=np.int32)
+            first, pending = 0, None
+            while first < n_pairs:
+                saved = np.random.get_state()
+                draw_stream(first, pending=pending)
+                after = np.random.get_state()
+                n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first, mean_only=mean_only)
+                n_inv_all[first:] = n_inv
+                event = (n_inv > 0).any(axis=1)
+                if resample_rep:
+                    event |= (n_inv < 0).any(axis=1) & ~known_bad[first:]      # a group without valid replicates shrinks num_rep
+                needs = np.flatnonzero((~skip[first:]) & event) + first
+                if len(needs) == 0:
+                    np.random.set_state(after)
+                    pending = None
+                    break
+                p = int(needs[0])
+                np.random.set_state(saved)
+                draw_stream(first, stop_pair=p, pending=pending)                # everything the reference drew up to pair p's hash
+                for t, col in ((bs.ym, 0), (bs.yv, 1)):
+                    if n_inv_all[p, col] > 0:
+                        row = engine.host(t[p, 1:])
+                        t[p, 1:] = engine.dev(_host_fill(row))
+                        n_inv_all[p, col] = 0
+                if (n_inv_all[p] < 0).any():
+                    known_bad[p] = True
+                pending = p // ng if (resample_rep and p % ng == ng - 1) else None
+                first = p + 1
+            if pending is not None:
+                draw_assignments(pending)
+            bad_fill = (n_inv_all < 0).any(axis=1)
+
+        active_all = (~skip) & (bs.K >= 2)                       # bootstrap.py:97-98: a single bin gives NaN replicates
+        good = (active_all & ~bad_fill).reshape(G, ng)           # hypothesis_test.py:193-200
+
+        # tests: gene-major x treatment column (main.py:399-404)
+        test_gene, test_rows = [], []
+        cache = {}
         for gi in range(G):
-            cols = None if treatment_for_gene is None else [trt_cols.index(c) for c in treatment_for_gene[names[gi]]]
-            t = trt_all if cols is None else trt_all[:, cols]
+            if treatment_for_gene is None:
+                cols = None
+                nt = trt_all.shape[1]
+            else:
+                cols = [trt_cols.index(c) for c in treatment_for_gene[names[g0 + gi]]]
+                nt = len(cols)
             key = (good[gi].tobytes(), None if cols is None else tuple(cols))
-            if key not in masks:
-                Mg, ttg = _design.residual_parts(cov, t, Nc_list, good[gi])
-                masks[key] = (len(Ms), ttg)
-                Ms.append(Mg)
-            gene_mask[gi], ttg = masks[key]
-            nt = t.shape[1]
-            allones = good[gi].any() and (t[good[gi]] == 1).mean() == 1
-            tt_rows.append(ttg)
-            rr_test[ti:ti + nt] = not allones
-            ti += nt
-        tt_mat = np.concatenate(tt_rows, axis=0)
-        Mstack = np.stack(Ms)
-    for which, tag in ((0, 'mean'), (1, 'var')):
-        coef, stt = bs.contract(test_gene, Wmat, good, which)                                         # K9+K10
-        if use_rr and rr_test.any():
-            coef_r, stt_r = bs.contract_resampled(test_gene, tt_mat, good, which, gene_mask, Mstack, Nc_list,
-                                                  rep_assign, bcol_assign, seed=fill_seed + 17)
-            stt = np.where(rr_test[:, None], stt_r, stt)
-            rr_idx = engine.dev(np.flatnonzero(rr_test))
-            coef[rr_idx] = coef_r[rr_idx]
-        no_group = ~good[np.asarray(test_gene, dtype=np.int64)].any(axis=1) if n_tests else np.zeros(0, bool)
-        c0, se = stt[:, 0].copy(), stt[:, 1].copy()
-        p = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
-        c0[no_group], se[no_group], p[no_group] = np.nan, np.nan, np.nan                              # hypothesis_test.py:203-204
-        out[tag + '_coef'], out[tag + '_se'], out[tag + '_asl'] = c0, se, p
+            W = cache.get(key)
+            if W is None:
+                t = trt_all if cols is None else trt_all[:, cols]
+                W = _design.weight_rows(cov, t, Nc_list, good[gi])
+                if W.shape[0] != nt:
+                    W = np.repeat(W[:1], nt, axis=0)
+                cache[key] = W
+            test_gene.extend([gi] * nt)
+            test_rows.append(W)
+        n_tests = len(test_gene)
+        Wmat = np.concatenate(test_rows, axis=0) if test_rows else np.zeros((0, ng))
+        out = {}
+        use_rr = resample_rep and n_tests > 0
+        if use_rr:
+            # residual maker / residualised treatment per valid-group mask; tests whose treatment is all ones keep the
+            # weighted-average branch (hypothesis_test.py:262-265) and are not resampled
+            masks, gene_mask, tt_rows, rr_test = {}, np.zeros(G, dtype=np.int32), [], np.zeros(n_tests, dtype=bool)
+            Ms = []
+            ti = 0
+            for gi in range(G):
+                cols = None if treatment_for_gene is None else [trt_cols.index(c) for c in treatment_for_gene[names[g0 + gi]]]
+                t = trt_all if cols is None else trt_all[:, cols]
+                key = (good[gi].tobytes(), None if cols is None else tuple(cols))
+                if key not in masks:
+                    Mg, ttg = _design.residual_parts(cov, t, Nc_list, good[gi])
+                    masks[key] = (len(Ms), ttg)
+                    Ms.append(Mg)
+                gene_mask[gi], ttg = masks[key]
+                nt = t.shape[1]
+                allones = good[gi].any() and (t[good[gi]] == 1).mean() == 1
+                tt_rows.append(ttg)
+                rr_test[ti:ti + nt] = not allones
+                ti += nt
+            tt_mat = np.concatenate(tt_rows, axis=0)
+            Mstack = np.stack(Ms)
+        for which, tag in ((0, 'mean'), (1, 'var')):
+            coef, stt = bs.contract(test_gene, Wmat, good, which)                                         # K9+K10
+            if use_rr and rr_test.any():
+                coef_r, stt_r = bs.contract_resampled(test_gene, tt_mat, good, which, gene_mask, Mstack, Nc_list,
+                                                      rep_assign, bcol_assign, seed=fill_seed + 17)
+                stt = np.where(rr_test[:, None], stt_r, stt)
+                rr_idx = engine.dev(np.flatnonzero(rr_test))
+                coef[rr_idx] = coef_r[rr_idx]
+            no_group = ~good[np.asarray(test_gene, dtype=np.int64)].any(axis=1) if n_tests else np.zeros(0, bool)
+            c0, se = stt[:, 0].copy(), stt[:, 1].copy()
+            p = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
+            c0[no_group], se[no_group], p[no_group] = np.nan, np.nan, np.nan                              # hypothesis_test.py:203-204
+            out[tag + '_coef'], out[tag + '_se'], out[tag + '_asl'] = c0, se, p
+        st.last_bootstrap = bs
+        st.last_assignments = (rep_assign, bcol_assign)
+        return out
+
+    G_all = len(st.gene_idx)
+    chunk = G_all if strict else max(1, int(max_rows) // max(1, ng))   # strict replay is sequential over all genes
+    parts = [run_range(g0, min(G_all, g0 + chunk)) for g0 in range(0, G_all, chunk)] if G_all else []
+    keys = ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')
+    out = {k: (np.concatenate([p_[k] for p_ in parts]) if parts else np.zeros(0)) for k in keys}
     m['1d_ht'] = {}
     if treatment_for_gene is not None:
         m['1d_ht']['treatment_for_gene'] = treatment_for_gene
@@ -519,8 +531,6 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     m['1d_ht']['covariate'] = covariate
     for k in ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl'):
         m['1d_ht'][k] = out[k]
-    st.last_bootstrap = bs
-    st.last_assignments = (rep_assign, bcol_assign)
     if not inplace:
         return adata
 
@@ -617,7 +627,7 @@ def get_corr_matrix(adata, group):
 
 
 def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=3, num_cpus=1,
-                  **kwargs):
+                  max_rows=1 << 18, **kwargs):
     """Bootstrap hypothesis test of correlation differences (reference: memento/main.py:418-520,
     hypothesis_test._ht_2d :303-364).  Same replay semantics as ht_1d_moments."""
     if 'resampling' not in kwargs:
@@ -654,7 +664,6 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     slot = {int(g): i for i, g in enumerate(st.cols_local)}
     c1 = np.array([slot[int(idx1[c])] for c in first], dtype=np.int64)
     c2 = np.array([slot[int(idx2[c])] for c in first], dtype=np.int64)
-    bs = engine.Bootstrap2D(st.cols, c1, c2, st.maxx, st.sf_bin, st.sf_table, gq, num_boot)
     true_corr = np.stack([m['2d_moments'][g]['corr'][first] for g in groups], axis=1) if P_ else np.zeros((0, ng))   # [pair][group]
     with np.errstate(invalid="ignore"):
         skip = np.isnan(true_corr) | (np.abs(true_corr) == 1)                                  # hypothesis_test.py:325
@@ -662,32 +671,39 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     u = np.random.random(3 * int(live.sum()))            # r = random(2) then r0 = random() per live (pair, group), in order
     r1a, r1b, r0 = (np.zeros(P_ * ng) for _ in range(3))
     r1a[live], r1b[live], r0[live] = u[0::3], u[1::3], u[2::3]
-    so = bs.order                                         # device pair order (sorted by left column)
-
-    def to_dev_order(a):
-        return a.reshape(P_, ng)[so].reshape(-1)
-
-    bs.run(to_dev_order(skip.reshape(-1)), to_dev_order(r1a), to_dev_order(r1b), to_dev_order(r0),
-           to_dev_order(np.where(skip, np.nan, true_corr).reshape(-1)))
-    good = bs.active.reshape(P_, ng)                      # device order
-    cache = {}
-    rows = []
-    for k in range(P_):
-        key = good[k].tobytes()
-        W = cache.get(key)
-        if W is None:
-            W = cache[key] = _design.weight_rows(cov, trt, Nc_list, good[k])[:1]
-        rows.append(W)
-    Wmat = np.concatenate(rows, axis=0) if rows else np.zeros((0, ng))
-    coef, stt = bs.contract(np.arange(P_), Wmat, good)
-    pvals = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
     corr_coef, corr_se, corr_asl = (np.full(n_conv, np.nan) for _ in range(3))
-    for k in range(P_):
-        c = int(first[so[k]])
-        if not good[k].any():
-            continue
-        for cc in members[frozenset((int(idx1[c]), int(idx2[c])))]:
-            corr_coef[cc], corr_se[cc], corr_asl[cc] = stt[k, 0], stt[k, 1], pvals[k]
+    bs = None
+    # pairs are independent: process them in chunks so the replicate rows ([pair x group][B+1] fp64) stay bounded
+    chunk = max(1, int(max_rows) // max(1, ng))
+    for lo in range(0, P_, chunk):
+        hi = min(P_, lo + chunk)
+        n_ch = hi - lo
+        bs = engine.Bootstrap2D(st.cols, c1[lo:hi], c2[lo:hi], st.maxx, st.sf_bin, st.sf_table, gq, num_boot)
+        so = bs.order                                     # device pair order (sorted by left column)
+        sl = slice(lo * ng, hi * ng)
+
+        def to_dev_order(a):
+            return a[sl].reshape(n_ch, ng)[so].reshape(-1)
+
+        bs.run(to_dev_order(skip.reshape(-1)), to_dev_order(r1a), to_dev_order(r1b), to_dev_order(r0),
+               to_dev_order(np.where(skip, np.nan, true_corr).reshape(-1)))
+        good = bs.active.reshape(n_ch, ng)                # device order
+        cache, rows = {}, []
+        for k in range(n_ch):
+            key = good[k].tobytes()
+            W = cache.get(key)
+            if W is None:
+                W = cache[key] = _design.weight_rows(cov, trt, Nc_list, good[k])[:1]
+            rows.append(W)
+        Wmat = np.concatenate(rows, axis=0) if rows else np.zeros((0, ng))
+        coef, stt = bs.contract(np.arange(n_ch), Wmat, good)
+        pvals = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
+        for k in range(n_ch):
+            c = int(first[lo + so[k]])
+            if not good[k].any():
+                continue
+            for cc in members[frozenset((int(idx1[c]), int(idx2[c])))]:
+                corr_coef[cc], corr_se[cc], corr_asl[cc] = stt[k, 0], stt[k, 1], pvals[k]
     m['2d_ht'] = {'treatment': treatment, 'covariate': covariate, 'corr_coef': corr_coef, 'corr_se': corr_se, 'corr_asl': corr_asl}
     st.last_bootstrap2d = bs
     if not inplace:

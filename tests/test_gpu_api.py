@@ -104,6 +104,17 @@ def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     ok = np.isfinite(g["ht_mean_se"])
     assert np.median(np.abs(ht["mean_se"][ok] / g["ht_mean_se"][ok] - 1)) < 0.1
     assert np.median(np.abs(ht["var_se"][ok] / g["ht_var_se"][ok] - 1)) < 0.15
+    # gene-chunked execution (bounded replicate buffers) consumes the same stream in the same order
+    whole = {k: ht[k].copy() for k in ("mean_coef", "mean_se", "var_coef", "mean_asl")}
+    np.random.seed(int(g["ht_seed"]))
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=False, max_rows=40)
+    ht = adata.uns["memento"]["1d_ht"]
+    np.testing.assert_allclose(ht["mean_coef"], whole["mean_coef"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(ht["var_coef"], whole["var_coef"], rtol=1e-12, equal_nan=True)
+    same = ht["mean_se"] == whole["mean_se"]
+    assert same.mean() > 0.5            # genes without refilled replicates are bit-identical; the rest differ only by refill draws
+    np.testing.assert_allclose(ht["mean_se"], whole["mean_se"], rtol=0.2, equal_nan=True)
 
 
 def test_ht_1d_resample_rep(api_small):
@@ -181,6 +192,12 @@ def test_2d_moments_ht_and_corr_matrix_match_reference(api_small):
     np.testing.assert_allclose(ht["corr_coef"], g["ht2_corr_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
     np.testing.assert_allclose(ht["corr_se"], g["ht2_corr_se"], rtol=1e-8, equal_nan=True)
     np.testing.assert_allclose(ht["corr_asl"], g["ht2_corr_asl"], rtol=1e-5, equal_nan=True)
+    np.random.seed(int(g["ht_seed"]) + 1)                       # pair-chunked execution: identical results
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=False, max_rows=12)
+    np.testing.assert_allclose(m["2d_ht"]["corr_coef"], g["ht2_corr_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(m["2d_ht"]["corr_asl"], g["ht2_corr_asl"], rtol=1e-5, equal_nan=True)
+    ht = m["2d_ht"]
     df = memento.get_2d_ht_result(adata)
     assert list(df.columns) == ["gene_1", "gene_2", "corr_coef", "corr_se", "corr_pval"]
     g2 = memento.get_2d_moments(adata, groupby="cond")
