@@ -14,11 +14,11 @@
 #define K1_THREADS 1024
 #endif
 #ifndef K1_UNROLL
-#define K1_UNROLL 4
+#define K1_UNROLL 8
 #endif
 #define K1_MAX_SLICES 1024  // G <= 65536
 #ifndef K1_PIPE
-#define K1_PIPE 1
+#define K1_PIPE 0
 #endif
 #ifndef K1_WGS
 #define K1_WGS 2048  // target workgroups per launch
