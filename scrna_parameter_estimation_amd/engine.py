@@ -317,6 +317,31 @@ class Bootstrap1D:
         bi, xi = np.nonzero(tab)
         return bi, xi, tab[bi, xi]
 
+    def _order_on_host(self, p, r1, r0, slot, tile_ptr, ops):
+        """Replay order + bootstrap operands of ONE pair computed on the host (same arithmetic as k_bins_order:
+        code = count*r1 + r0*approx_sf ascending; pk = pix/remaining_p; log(1-p)) and written into its tile lane."""
+        torch = _torch()
+        bi, xi, mu = self.bins_of_pair(p)
+        code = xi.astype(np.float64) * r1 + r0 * self.sf_table[bi]
+        o = np.argsort(code, kind="stable")
+        if len(o) > 1 and (np.diff(code[o]) == 0).any():
+            raise NotImplementedError("two bins of one pair collided in the replay hash (np.unique would merge them)")
+        bi, xi, mu = bi[o], xi[o].astype(np.float64), mu[o].astype(np.float64)
+        pix = mu / float(self.blocks.grp_ncells[p % self.ng])
+        rem = np.empty_like(pix)
+        acc = 1.0
+        for k in range(len(pix)):      # sequential rounding, exactly like numpy's remaining_p
+            rem[k] = acc
+            acc -= pix[k]
+        pk = pix / rem
+        peff = np.where(pk <= 0.5, pk, 1.0 - pk)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lq = np.log(1.0 - peff)
+        sf = self.sf_table[bi]
+        idx = dev((int(tile_ptr[slot >> 6]) + np.arange(len(pk), dtype=np.int64)) * 64 + (slot & 63))
+        for arr, vals in zip(ops, (pk, lq, xi, 1.0 / sf, 1.0 / (sf * sf))):
+            arr[idx] = dev(vals)
+
     def alloc_outputs(self, true_mean_log, true_rv_log):
         """ym/yv [n_pairs][B+1] = NaN, column 0 = log true mean / log true residual variance (hypothesis_test.py:174)."""
         torch = _torch()
@@ -338,8 +363,6 @@ class Bootstrap1D:
         active = (~np.asarray(skip, dtype=bool)) & (self.K >= 2)
         active[:first_pair] = False
         act = np.flatnonzero(active)
-        if len(act) and (self.K[act] > ORDER_BIG_CAP).any():
-            raise NotImplementedError(f"a (gene, group) pair has more than {ORDER_BIG_CAP} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         n_act = len(order)
         # replay: cost-model lane packing (one lane = one sequential chain); fast: dense 64-wide tiles (one WAVE per pair)
@@ -361,13 +384,16 @@ class Bootstrap1D:
         d_r1, d_r0 = dev(np.asarray(r1, dtype=np.float64)), dev(np.asarray(r0, dtype=np.float64))
         d_sf, d_nc = dev(self.sf_table), dev(self.blocks.grp_ncells.astype(np.float64))
         small = order[self.K[order] <= ORDER_SMALL_CAP]
-        big = order[self.K[order] > ORDER_SMALL_CAP]
+        big = order[(self.K[order] > ORDER_SMALL_CAP) & (self.K[order] <= ORDER_BIG_CAP)]
+        huge = order[self.K[order] > ORDER_BIG_CAP]
         for lst, is_big in ((small, 0), (big, 1)):
             if len(lst):
                 d_lst = dev(lst)
                 _lib.call("mm_bins_order", P(self.tab), P(self.d_tab_ptr), P(self.d_xcap), P(self.d_K), P(d_lst), len(lst),
                           is_big, ng, self.n_bins, P(d_sf), P(d_r1), P(d_r0), P(d_pair_slot), P(d_tile_ptr), P(d_nc),
                           *[P(o) for o in ops], P(status), s)
+        for p in huge:   # more bins than the in-LDS sort holds (very highly expressed genes): order them on the host
+            self._order_on_host(int(p), float(r1[p]), float(r0[p]), int(pair_slot[p]), tile_ptr, ops)
         nobs = np.zeros(n_tiles * 64, dtype=np.float64)
         nobs[slot_of] = self.blocks.grp_ncells[order % ng]
         omq = np.zeros(n_tiles * 64, dtype=np.float64)

@@ -119,6 +119,13 @@ def test_plan_blocks():
     assert cell0[-1] == len(order)
 
 
+def test_fdrcorrect_matches_bh():
+    from scrna_parameter_estimation_amd.memento.util import _fdrcorrect
+
+    p = np.array([0.01, 0.04, np.nan, 0.03, 0.5, 0.002])
+    np.testing.assert_allclose(_fdrcorrect(p), [0.025, 0.05, 1.0, 0.05, 0.5, 0.01])
+
+
 GLOO_SCRIPT = r"""
 import os, sys
 sys.path.insert(0, %r)

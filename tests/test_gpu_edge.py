@@ -1,0 +1,99 @@
+"""Edge cases on the GPU path: empty genes / cells, a gene expressed in one group only, tiny groups, cells outside
+every group, single-bin pairs, and the host ordering fallback for pairs with more bins than the LDS sort holds."""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from scrna_parameter_estimation_amd import engine
+
+    engine._lib.load(require_gpu=True)
+    return engine
+
+
+def _edge_matrix():
+    rng = np.random.default_rng(42)
+    n, g = 700, 40
+    X = rng.poisson(0.6, size=(n, g)).astype(np.float32)
+    X[:, 3] = 0                      # gene never expressed
+    gid = rng.integers(0, 3, size=n).astype(np.int32)
+    gid[:6] = 3                      # a 6-cell group
+    gid[6:20] = -1                   # cells in no group
+    X[gid == 1, 5] = 0               # gene 5 silent in group 1
+    X[gid != 0, 7] = 0               # gene 7 expressed in group 0 only
+    X[30:40, :] = 0                  # empty cells
+    X[50, 9] = 300                   # one large count
+    return sp.csr_matrix(X), gid, 4
+
+
+def test_edge_moments_and_bins(eng):
+    from oracle import memento_oracle as orc
+
+    X, gid, ng = _edge_matrix()
+    rng = np.random.default_rng(1)
+    sf = rng.lognormal(0, 0.4, size=X.shape[0])
+    blocks = eng.CountBlocks(eng.DeviceCSR(X), gid, ng)
+    S, sumx, maxx = blocks.moments(1.0 / sf)
+    X64 = X.astype(np.float64).tocsc()
+    for k in range(ng):
+        sel = np.flatnonzero(gid == k)
+        w = 1.0 / sf[sel]
+        np.testing.assert_allclose(S[0, k], X64[sel].T.dot(w), rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(S[1, k], X64[sel].power(2).T.dot(w ** 2), rtol=1e-12, atol=1e-300)
+        np.testing.assert_array_equal(sumx[k], np.asarray(X64[sel].sum(axis=0)).ravel().astype(np.uint64))
+        np.testing.assert_array_equal(maxx[k], np.asarray(X64[sel].max(axis=0).todense()).ravel().astype(np.uint32))
+    assert maxx[:, 3].max() == 0 and sumx[1, 5] == 0 and sumx[1:, 7].sum() == 0 and maxx.max() == 300
+    # bins: 3 size-factor bins, every gene tested
+    edges = np.quantile(sf, [1 / 3, 2 / 3])
+    sf_bin = np.digitize(sf, edges).astype(np.uint8)
+    sf_table = np.array([sf[sf_bin == b].mean() for b in range(3)])
+    bs = eng.Bootstrap1D(blocks, np.arange(X.shape[1]), maxx, sf_bin, sf_table, np.full(ng, 0.1), 32)
+    Xd = X.toarray()
+    for gene in (3, 5, 7, 9, 0):
+        for k in range(ng):
+            sel = np.flatnonzero(gid == k)
+            _, _, expr, mult = orc.unique_bins_1d(Xd[sel, gene].astype(np.float64), sf_table[sf_bin[sel]], 0.3, 0.7)
+            bi, xi, mu = bs.bins_of_pair(gene * ng + k)
+            assert sorted(zip(xi.tolist(), mu.tolist())) == sorted(zip(expr.astype(int).tolist(), mult.tolist()))
+            assert mu.sum() == len(sel) and bs.K[gene * ng + k] == len(mult)
+
+
+def test_replay_weights_edge_and_host_order_fallback(eng, monkeypatch):
+    from oracle import memento_oracle as orc
+
+    X, gid, ng = _edge_matrix()
+    rng = np.random.default_rng(2)
+    sf = rng.lognormal(0, 0.4, size=X.shape[0])
+    blocks = eng.CountBlocks(eng.DeviceCSR(X), gid, ng)
+    S, sumx, maxx = blocks.moments(1.0 / sf)
+    sf_bin = np.digitize(sf, np.quantile(sf, [0.25, 0.5, 0.75])).astype(np.uint8)
+    sf_table = np.array([sf[sf_bin == b].mean() for b in range(4)])
+    B = 24
+    Xd = X.toarray().astype(np.float64)
+    results = []
+    for caps in ((1024, 8192), (4, 6)):     # second pass: almost every pair goes through the big / host ordering paths
+        monkeypatch.setattr(eng, "ORDER_SMALL_CAP", caps[0])
+        monkeypatch.setattr(eng, "ORDER_BIG_CAP", caps[1])
+        bs = eng.Bootstrap1D(blocks, np.arange(X.shape[1]), maxx, sf_bin, sf_table, np.full(ng, 0.1), B)
+        r = np.random.default_rng(5).random((2, bs.n_pairs))
+        zeros = np.zeros(bs.n_pairs)
+        bs.alloc_outputs(zeros, zeros)
+        bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
+        wd = eng.host(bs.w_dump)
+        rm = eng.host(bs.raw_mean)
+        for p in range(bs.n_pairs):
+            gene, k = divmod(p, ng)
+            sel = np.flatnonzero(gid == k)
+            inv_sf, inv_sf_sq, expr, mult = orc.unique_bins_1d(Xd[sel, gene], sf_table[sf_bin[sel]], r[0][p], r[1][p])
+            if len(expr) <= 1:
+                assert np.isnan(rm[p, 1:]).all()          # bootstrap.py:97-98
+                continue
+            w = orc.multinomial_weights(len(sel), mult, B)
+            np.testing.assert_array_equal(wd[bs.pair_slot[p], :len(expr), :], w, err_msg=f"pair {p} caps {caps}")
+        results.append(rm)
+    np.testing.assert_array_equal(results[0], results[1])  # device-ordered and host-ordered operands give identical replicates
