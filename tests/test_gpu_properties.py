@@ -89,3 +89,33 @@ def test_histograms_and_multinomial_invariants(big):
     # replicate means are non-negative and finite; bootstrap mean of the replicate means is close to the estimate
     rm = engine.host(bs.raw_mean)[:, 1:]
     assert np.isfinite(rm[bs.active]).all() and (rm[bs.active] >= 0).all()
+
+
+def test_replay_weights_bit_exact_at_scale(big):
+    """BTPE-heavy stress of the margin-guarded samplers on the device: ~2e6 draws on 12k-cell groups must equal
+    numpy's Generator(PCG64(5)).multinomial draw for draw."""
+    engine, torch, csr, gid, blocks, sf = big
+    S, sumx, maxx = blocks.moments(1.0 / sf)
+    rng = np.random.default_rng(3)
+    dense = np.flatnonzero(sumx.sum(axis=0) > 20000)
+    genes = np.sort(rng.choice(dense, size=min(24, len(dense)), replace=False))
+    n_bins = 31
+    sf_bin = rng.integers(0, n_bins, size=csr.shape[0]).astype(np.uint8)
+    sf_table = np.linspace(0.4, 2.5, n_bins)
+    B = 96
+    bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(8, 0.07), B)
+    r = rng.random((2, bs.n_pairs))
+    zeros = np.zeros(bs.n_pairs)
+    bs.alloc_outputs(zeros, zeros)
+    bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
+    wd = engine.host(bs.w_dump)
+    n_draws = 0
+    for p in range(bs.n_pairs):
+        bi, xi, mu = bs.bins_of_pair(p)
+        code = xi.astype(np.float64) * r[0][p] + r[1][p] * sf_table[bi]
+        o = np.argsort(code, kind="stable")
+        mult = mu[o].astype(np.int64)
+        want = np.random.Generator(np.random.PCG64(5)).multinomial(int(blocks.grp_ncells[p % 8]), mult / mult.sum(), size=B).T
+        np.testing.assert_array_equal(wd[bs.pair_slot[p], :len(mult), :], want, err_msg=f"pair {p}")
+        n_draws += (len(mult) - 1) * B
+    assert n_draws > 1_000_000
