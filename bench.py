@@ -45,8 +45,8 @@ def synth_device_csr(cfg, seed, torch):
 
     N, G, dens = cfg["cells"], cfg["genes"], cfg["density"]
     rng = np.random.default_rng(seed)
-    mu = rng.lognormal(-2.2, 1.2, size=G)
-    depth = rng.lognormal(0.0, 0.35, size=N)
+    mu = rng.lognormal(-2.2, 1.2, size=G)                                  # genes: differ per rank (gene shards)
+    depth = np.random.default_rng(20250117).lognormal(0.0, 0.35, size=N)   # cells: the SAME cells on every rank
     nodes = np.quantile(depth, (np.arange(64) + 0.5) / 64)
     w = np.full(64, 1.0 / 64)
     lo, hi = 1e-4, 1e4
