@@ -19,8 +19,9 @@ ORDER_BIG_CAP = 8192
 ORDER_BIG_CAP_2D = 4096
 # lane-packing cost model of the replay kernel (instructions per bin step: C0 + C1 * active lanes)
 PACK_C0 = float(__import__('os').environ.get('MM_PACK_C0', 250))
-PACK_C1 = float(__import__('os').environ.get('MM_PACK_C1', 14))
-PACK_WAVES = int(__import__('os').environ.get('MM_PACK_WAVES', 1024))
+PACK_C1 = float(__import__('os').environ.get('MM_PACK_C1', 4))
+# ~2 waves on each of the 1024 SIMDs: measured optimum on C2 and C3 (profiles/README.md); fewer idles SIMDs, more adds a partial round
+PACK_WAVES = int(__import__('os').environ.get('MM_PACK_WAVES', 2000))
 
 
 def _torch():
