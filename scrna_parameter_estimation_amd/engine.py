@@ -6,6 +6,7 @@ include/memento_hip.h.  Nothing in this module has a CPU fallback.
 """
 
 import ctypes
+import os
 from ctypes import c_void_p
 
 import numpy as np
@@ -18,10 +19,10 @@ ORDER_SMALL_CAP = 1024
 ORDER_BIG_CAP = 8192
 ORDER_BIG_CAP_2D = 4096
 # lane-packing cost model of the replay kernel (instructions per bin step: C0 + C1 * active lanes)
-PACK_C0 = float(__import__('os').environ.get('MM_PACK_C0', 250))
-PACK_C1 = float(__import__('os').environ.get('MM_PACK_C1', 4))
+PACK_C0 = float(os.environ.get('MM_PACK_C0', 250))
+PACK_C1 = float(os.environ.get('MM_PACK_C1', 4))
 # ~2 waves on each of the 1024 SIMDs: measured optimum on C2 and C3 (profiles/README.md); fewer idles SIMDs, more adds a partial round
-PACK_WAVES = int(__import__('os').environ.get('MM_PACK_WAVES', 2000))
+PACK_WAVES = int(os.environ.get('MM_PACK_WAVES', 2000))
 
 
 def _torch():
