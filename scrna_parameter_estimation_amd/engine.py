@@ -115,6 +115,13 @@ class DeviceCSR:
         return host(out)
 
 
+def auto_max_rows(ld, arrays=2, fraction=0.4):
+    """Rows of replicate buffers ([rows][ld] fp64, ``arrays`` of them plus one coefficient buffer) that fit in
+    ``fraction`` of the currently free HBM."""
+    free, _ = _torch().cuda.mem_get_info()
+    return max(1024, int(free * fraction) // (int(ld) * 8 * (arrays + 1)))
+
+
 def plan_blocks(group_id, n_groups, block_cells=BLOCK_CELLS):
     """Order cells by group (stable) and cut every group into near-equal blocks of <= block_cells.
 

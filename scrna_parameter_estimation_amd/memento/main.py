@@ -314,7 +314,7 @@ def _host_fill(row):
 
 
 def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=1, num_cpus=1,
-                  rng='replay', strict=False, fill_seed=0, max_rows=1 << 21, **kwargs):
+                  rng='replay', strict=False, fill_seed=0, max_rows=None, **kwargs):
     """Bootstrap hypothesis test of mean / residual-variance differences (reference: memento/main.py:341-415).
 
     ``rng='replay'``: the multinomial resampling replays numpy's ``Generator(PCG64(5))`` stream draw for
@@ -520,6 +520,8 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         return out
 
     G_all = len(st.gene_idx)
+    if max_rows is None:                       # replicate buffers sized to the free HBM (288 GB on MI355X)
+        max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
     chunk = G_all if strict else max(1, int(max_rows) // max(1, ng))   # strict replay is sequential over all genes
     parts = [run_range(g0, min(G_all, g0 + chunk)) for g0 in range(0, G_all, chunk)] if G_all else []
     keys = ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')
@@ -627,7 +629,7 @@ def get_corr_matrix(adata, group):
 
 
 def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=3, num_cpus=1,
-                  max_rows=1 << 18, **kwargs):
+                  max_rows=None, **kwargs):
     """Bootstrap hypothesis test of correlation differences (reference: memento/main.py:418-520,
     hypothesis_test._ht_2d :303-364).  Same replay semantics as ht_1d_moments."""
     if 'resampling' not in kwargs:
@@ -674,6 +676,8 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     corr_coef, corr_se, corr_asl = (np.full(n_conv, np.nan) for _ in range(3))
     bs = None
     # pairs are independent: process them in chunks so the replicate rows ([pair x group][B+1] fp64) stay bounded
+    if max_rows is None:
+        max_rows = min(1 << 19, engine.auto_max_rows(num_boot + 1, arrays=1))   # also bounds the per-pair 2D tables
     chunk = max(1, int(max_rows) // max(1, ng))
     for lo in range(0, P_, chunk):
         hi = min(P_, lo + chunk)

@@ -119,3 +119,33 @@ def test_replay_weights_bit_exact_at_scale(big):
         np.testing.assert_array_equal(wd[bs.pair_slot[p], :len(mult), :], want, err_msg=f"pair {p}")
         n_draws += (len(mult) - 1) * B
     assert n_draws > 1_000_000
+
+
+@pytest.mark.parametrize("rng_mode", ["replay", "fast"])
+def test_null_calibration(rng_mode):
+    """Statistical acceptance (the reference validates itself this way, analysis/simulation/calibration.ipynb): with
+    group labels independent of the counts, DE p-values are uniform -- for the numpy-replay mode and for the
+    replicate-parallel fast mode alike."""
+    import pandas as pd
+    import scipy.stats as stats
+
+    from scrna_parameter_estimation_amd import memento
+    from scrna_parameter_estimation_amd.synth import synth_adata
+
+    adata = synth_adata(24000, 900, 0.12, 2, 3, seed=101, dtype=np.float32)
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": gdf["cond"].astype(float)}, index=gdf.index)
+    np.random.seed(4)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=2000, num_cpus=1, verbose=0, resampling="bootstrap",
+                          approx=True, rng=rng_mode, fill_seed=11)
+    p = adata.uns["memento"]["1d_ht"]["mean_asl"]
+    p = p[np.isfinite(p)]
+    assert len(p) > 300
+    chi2 = stats.chi2.isf(p, 1)
+    lam = np.median(chi2) / stats.chi2.ppf(0.5, 1)          # genomic inflation factor; the reference reports 0.9956
+    assert 0.75 < lam < 1.3, lam
+    assert stats.kstest(p, "uniform").pvalue > 1e-4
