@@ -33,6 +33,9 @@ CONFIGS = {
     "C3": dict(cells=1_000_000, genes=20_000, density=0.03, n_cond=2, n_rep=10, num_boot=10_000),
     "tiny": dict(cells=6_000, genes=400, density=0.08, n_cond=2, n_rep=2, num_boot=200),
     # scaled-down shapes of configs[3] / [4] for sanity runs (not headline): many groups; see tools/bench_2d.py for 2D
+    # shapes of the reference's own published timings, for context in DESIGN.md
+    "tutorial": dict(cells=5_341, genes=7_000, density=0.10, n_cond=2, n_rep=1, num_boot=5_000),      # ifn_mono_ht.ipynb: 53.2 s / 1877 genes
+    "runtime1M": dict(cells=1_000_000, genes=12_000, density=0.06, n_cond=2, n_rep=1, num_boot=1_000),  # runtime/plots.ipynb: 0.1113 s/gene
     "G36k": dict(cells=150_000, genes=36_601, density=0.02, n_cond=3, n_rep=1, num_boot=300),   # > 32768 genes: tiled ingest counters
     "C5s": dict(cells=60_000, genes=3_000, density=0.05, n_cond=101, n_rep=1, num_boot=500),
 }
