@@ -161,3 +161,56 @@ def test_gene_sharded_exchange_gloo_world2(tmp_path):
                         "--master-port", "29533", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_api_error_conventions_before_touching_the_device():
+    """Same exception types as the reference for bad input: AssertionError for q >= 1 and non-CSR X
+    (main.py:42-44), TypeError when `resampling` is missing (hypothesis_test.py:57) -- all raised before any HIP call."""
+    import pandas as pd
+    import scipy.sparse as sp
+
+    from scrna_parameter_estimation_amd import AnnDataLite, memento
+
+    X = sp.random(50, 8, density=0.3, format="csr", dtype=np.float32)
+    X.data[:] = 1
+    obs = pd.DataFrame({"q": np.full(50, 1.2), "g": np.arange(50) % 2})
+    ad = AnnDataLite(X, obs)
+    with pytest.raises(AssertionError):
+        memento.setup_memento(ad, q_column="q")
+    ad.obs["q"] = 0.1
+    ad.X = X.tocsc()
+    with pytest.raises(AssertionError):
+        memento.setup_memento(ad, q_column="q")
+    ad.uns["memento"] = {}
+    cov = pd.DataFrame({"i": [1.0, 1.0]})
+    with pytest.raises(TypeError):
+        memento.ht_1d_moments(ad, covariate=cov, treatment=cov)
+    with pytest.raises(TypeError):
+        memento.ht_2d_moments(ad, covariate=cov, treatment=cov)
+    with pytest.raises(AssertionError):
+        memento.compute_1d_moments(AnnDataLite(X, obs.copy()))       # setup_memento was not run (main.py:181)
+    with pytest.raises(TypeError):
+        AnnDataLite(X.toarray())
+
+
+def test_public_api_names_match_reference():
+    """The 13 names the reference re-exports (memento/__init__.py:1) exist with the reference's leading parameters."""
+    import inspect
+
+    from scrna_parameter_estimation_amd import memento
+
+    want = {
+        "setup_memento": ["adata", "q_column", "inplace", "filter_mean_thresh", "trim_percent", "shrinkage", "num_bins", "estimator_type"],
+        "create_groups": ["adata", "label_columns", "label_delimiter", "inplace"],
+        "compute_1d_moments": ["adata", "inplace", "min_perc_group", "filter_genes", "gene_list"],
+        "compute_2d_moments": ["adata", "gene_pairs", "inplace"],
+        "ht_1d_moments": ["adata", "covariate", "treatment", "treatment_for_gene", "inplace", "num_boot", "verbose", "num_cpus"],
+        "ht_2d_moments": ["adata", "covariate", "treatment", "treatment_for_gene", "inplace", "num_boot", "verbose", "num_cpus"],
+        "get_1d_moments": ["adata", "groupby"], "get_2d_moments": ["adata", "groupby"], "get_1d_ht_result": ["adata"],
+        "get_2d_ht_result": ["adata"], "prepare_to_save": ["adata", "keep"], "get_corr_matrix": ["adata", "group"], "get_groups": ["adata"],
+    }
+    for name, params in want.items():
+        got = list(inspect.signature(getattr(memento, name)).parameters)
+        assert got[: len(params)] == params, (name, got)
+    assert inspect.signature(memento.ht_1d_moments).parameters["num_boot"].default == 10000
+    assert inspect.signature(memento.setup_memento).parameters["filter_mean_thresh"].default == 0.07

@@ -206,6 +206,28 @@ def test_2d_moments_ht_and_corr_matrix_match_reference(api_small):
     np.testing.assert_allclose(cm, g["corr_matrix_g0"], rtol=1e-8, atol=1e-12, equal_nan=True)
 
 
+def test_inplace_false_and_prepare_to_save(api_small):
+    """inplace=False returns a copy and leaves the input untouched; prepare_to_save drops everything that cannot be
+    written to disk (device handles, per-group regressors) -- reference: main.py:39-40, :673-683."""
+    g = api_small
+    from scrna_parameter_estimation_amd import memento
+
+    adata = _adata_from_golden(g)
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    before = adata.shape
+    out = memento.compute_1d_moments(adata, min_perc_group=0.7, inplace=False)
+    assert adata.shape == before and "1d_moments" not in adata.uns["memento"]
+    assert out.shape[1] == len(g["gene_list"]) and "1d_moments" in out.uns["memento"]
+    np.testing.assert_allclose(out.uns["memento"]["1d_moments"][g["groups"][0]][0], g["mean"][0], rtol=1e-11)
+    memento.prepare_to_save(out)
+    m = out.uns["memento"]
+    assert "_hip" not in m and all(k not in m["mv_regressor"] for k in list(g["groups"]) + ["all"])
+    import pickle
+
+    pickle.dumps({k: v for k, v in m.items() if k not in ("1d_ht",)})          # plain python / numpy only
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from scrna_parameter_estimation_amd import _lib
 
