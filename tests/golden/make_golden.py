@@ -111,6 +111,25 @@ def api_case(name, n_cells, n_genes, density, n_cond, n_rep, seed, num_boot, ht_
                               resampling="bootstrap", approx=approx, resample_rep=True)
         for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
             out["htrr_" + k] = np.asarray(m["1d_ht"][k]).copy()
+    if name == "api_approx":
+        # richer design: a numeric covariate besides the intercept, two treatment columns, per-gene treatment subsets
+        rng2 = np.random.default_rng(seed + 3)
+        cov2 = pd.DataFrame({"intercept": np.ones(len(gdf)), "rep": gdf["rep"].astype(float).values}, index=gdf.index)
+        trt2 = pd.DataFrame({"cond": (gdf["cond"].astype(int) == n_cond - 1).astype(float).values,
+                             "dose": rng2.normal(size=len(gdf))}, index=gdf.index)
+        out["cov2"], out["trt2"] = cov2.values.copy(), trt2.values.copy()
+        np.random.seed(ht_seed + 4)
+        memento.ht_1d_moments(adata, covariate=cov2, treatment=trt2, num_boot=num_boot, num_cpus=1, verbose=0,
+                              resampling="bootstrap", approx=approx)
+        for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+            out["ht2t_" + k] = np.asarray(m["1d_ht"][k]).copy()
+        tfg = {gname: (["cond"] if i % 3 == 0 else (["dose"] if i % 3 == 1 else ["cond", "dose"])) for i, gname in enumerate(adata.var.index)}
+        out["tfg_pattern"] = np.array([i % 3 for i in range(adata.shape[1])])
+        np.random.seed(ht_seed + 5)
+        memento.ht_1d_moments(adata, covariate=cov2, treatment=trt2, treatment_for_gene=tfg, num_boot=num_boot, num_cpus=1,
+                              verbose=0, resampling="bootstrap", approx=approx)
+        for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+            out["httfg_" + k] = np.asarray(m["1d_ht"][k]).copy()
     out["ht_seed"] = np.int64(ht_seed)
     out["num_boot"] = np.int64(num_boot)
     out["approx"] = np.bool_(approx)

@@ -206,6 +206,33 @@ def test_2d_moments_ht_and_corr_matrix_match_reference(api_small):
     np.testing.assert_allclose(cm, g["corr_matrix_g0"], rtol=1e-8, atol=1e-12, equal_nan=True)
 
 
+def test_ht_1d_rich_design_and_treatment_for_gene(api_approx):
+    """Numeric covariate + two treatment columns, then per-gene treatment subsets (main.py:368-373, :389, :402):
+    strict replay against the real reference, result order gene-major x treatment."""
+    g = api_approx
+    memento, adata = _run_to_moments(g)
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame(g["cov2"], index=gdf.index, columns=["intercept", "rep"])
+    trt = pd.DataFrame(g["trt2"], index=gdf.index, columns=["cond", "dose"])
+    np.random.seed(int(g["ht_seed"]) + 4)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=True, strict=True)
+    ht = adata.uns["memento"]["1d_ht"]
+    assert len(ht["mean_coef"]) == 2 * len(g["gene_list"])
+    for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+        np.testing.assert_allclose(ht[k], g["ht2t_" + k], rtol=1e-5 if k.endswith("asl") else 1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+    names = list(adata.var.index)
+    tfg = {n: (["cond"] if i % 3 == 0 else (["dose"] if i % 3 == 1 else ["cond", "dose"])) for i, n in enumerate(names)}
+    np.random.seed(int(g["ht_seed"]) + 5)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, treatment_for_gene=tfg, num_boot=int(g["num_boot"]), num_cpus=1,
+                          verbose=0, resampling="bootstrap", approx=True, strict=True)
+    ht = adata.uns["memento"]["1d_ht"]
+    for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+        np.testing.assert_allclose(ht[k], g["httfg_" + k], rtol=1e-5 if k.endswith("asl") else 1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+    df = memento.get_1d_ht_result(adata)
+    assert len(df) == len(g["httfg_mean_coef"]) and list(df["tx"][:4]) == ["cond", "dose", "cond", "dose"]
+
+
 def test_inplace_false_and_prepare_to_save(api_small):
     """inplace=False returns a copy and leaves the input untouched; prepare_to_save drops everything that cannot be
     written to disk (device handles, per-group regressors) -- reference: main.py:39-40, :673-683."""
