@@ -190,6 +190,19 @@ int mm_cross_resampled(const double *d_yt, int64_t ld, int32_t num_boot, int32_t
                        const double *d_tt, const uint8_t *d_good, const double *d_Nc, const int16_t *d_rep, const int32_t *d_bcol,
                        uint64_t seed, int64_t n_tests, double *d_coef, double *d_stats, int32_t *d_status, void *stream);
 
+/* ---- two-group contrasts against a shared control (Perturb-seq batching) ---------------------
+ * test t: coef_b = y[test_gene[t], test_grp[t]][b] - y[test_gene[t], ctrl][b] -- what _regress_1d computes for the two
+ * groups {control, guide} with a binary treatment (hypothesis_test.py:269-291); the control's bootstrap is shared by all
+ * guides instead of being recomputed per guide as in the reference's per-guide loop.  stats layout as mm_contract_stats,
+ * for the mean and the variability response in one launch; nothing per-replicate is stored. */
+int mm_contrast_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups, int32_t ctrl,
+                      const int32_t *d_test_gene, const int32_t *d_test_grp, const uint8_t *d_good, int64_t n_tests,
+                      double *d_stats_mean, double *d_stats_var, void *stream);
+/* coefficient rows [n_tests][ld] of selected contrasts (NaN where a replicate column is dropped) for the tail fits */
+int mm_contrast_rows(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups, int32_t ctrl,
+                     const int32_t *d_test_gene, const int32_t *d_test_grp, int64_t n_tests, int32_t which, double *d_out,
+                     void *stream);
+
 /* ==== 2D (gene pairs) ===========================================================================
  * K11 step 1: copy the columns of the n_cols genes with d_col_id[gene] = m >= 0 out of the SELL blocks into a
  * gene-contiguous store: entries of (block b, column m) at d_out[col_ptr[b*(n_cols+1)+m] .. col_ptr[b*(n_cols+1)+m+1])

@@ -52,6 +52,10 @@ _SIGS = {
     "mm_boot1d_fast": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_boot_fill_log": ([c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_double), c_int32, c_uint64,
                           c_void_p, c_void_p], ctypes.c_int),
+    "mm_contrast_stats": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                           c_void_p], ctypes.c_int),
+    "mm_contrast_rows": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p],
+                         ctypes.c_int),
     "mm_residualize": ([c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_cross_resampled": ([c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),

@@ -302,6 +302,87 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-group contrasts against a shared control (Perturb-seq style, BASELINE config 5): test t compares group
+// test_grp[t] with the control group of gene test_gene[t]:  coef_b = y[gene, grp][b] - y[gene, ctrl][b]
+// (the weighted slope of _cross_coef for two groups and a binary treatment, hypothesis_test.py:218-228, reduces to this
+// difference).  The control's bootstrap rows are computed once and shared by every guide.  Nothing per-replicate is
+// stored: both passes recompute the difference from the resident replicate rows.  One launch does mean and variance.
+__global__ __launch_bounds__(K9_THREADS) void k_contrast_stats(const double *__restrict__ ym, const double *__restrict__ yv,
+                                                               int64_t ld, int32_t num_boot, int32_t n_groups, int32_t ctrl,
+                                                               const int32_t *__restrict__ test_gene, const int32_t *__restrict__ test_grp,
+                                                               const uint8_t *__restrict__ good, double *__restrict__ stats_m,
+                                                               double *__restrict__ stats_v) {
+  __shared__ double red[K9_THREADS / 64];
+  int64_t t = blockIdx.x;
+  int gene = test_gene[t], grp = test_grp[t];
+  double *sm_ = stats_m + t * 8, *sv_ = stats_v + t * 8;
+  const uint8_t *gd = good + (int64_t)gene * n_groups;
+  if (!gd[grp] || !gd[ctrl]) {
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 8; i++) {
+        sm_[i] = (i == 2 || i == 3 || i == 5) ? 0.0 : NAN;
+        sv_[i] = (i == 2 || i == 3 || i == 5) ? 0.0 : NAN;
+      }
+    }
+    return;
+  }
+  const double *ma = ym + ((int64_t)gene * n_groups + grp) * ld, *mc = ym + ((int64_t)gene * n_groups + ctrl) * ld;
+  const double *va = yv + ((int64_t)gene * n_groups + grp) * ld, *vc = yv + ((int64_t)gene * n_groups + ctrl) * ld;
+  int n_cols = num_boot + 1;
+  double sum_m = 0, sum_v = 0, cnt = 0, mn_m = INFINITY, mx_m = -INFINITY, mn_v = INFINITY, mx_v = -INFINITY;
+  for (int c = threadIdx.x; c < n_cols; c += K9_THREADS) {
+    double a = ma[c], b = mc[c], p = va[c], q = vc[c];
+    if (isfinite(a) && isfinite(b) && isfinite(p) && isfinite(q)) {
+      double dm = a - b, dv = p - q;
+      mn_m = fmin(mn_m, dm); mx_m = fmax(mx_m, dm);
+      mn_v = fmin(mn_v, dv); mx_v = fmax(mx_v, dv);
+      if (c > 0) { sum_m += dm; sum_v += dv; cnt += 1.0; }
+    }
+  }
+  double n = wg_sum(cnt, red);
+  double tm = wg_sum(sum_m, red), tv = wg_sum(sum_v, red);
+  double lo_m = wg_min(mn_m, red), hi_m = wg_max(mx_m, red), lo_v = wg_min(mn_v, red), hi_v = wg_max(mx_v, red);
+  double c0m = ma[0] - mc[0], c0v = va[0] - vc[0];
+  double mean_m = n > 0 ? tm / n : NAN, mean_v = n > 0 ? tv / n : NAN;
+  double am = fabs(c0m), av = fabs(c0v);
+  double sq_m = 0, sq_v = 0, ex_m = 0, ex_v = 0;
+  for (int c = 1 + threadIdx.x; c < n_cols; c += K9_THREADS) {
+    double a = ma[c], b = mc[c], p = va[c], q = vc[c];
+    if (isfinite(a) && isfinite(b) && isfinite(p) && isfinite(q)) {
+      double dm = a - b, dv = p - q;
+      sq_m += (dm - mean_m) * (dm - mean_m);
+      sq_v += (dv - mean_v) * (dv - mean_v);
+      double nm = dm - c0m, nv = dv - c0v;
+      if (nm > am || nm < -am) ex_m += 1.0;
+      if (nv > av || nv < -av) ex_v += 1.0;
+    }
+  }
+  double qm = wg_sum(sq_m, red), qv = wg_sum(sq_v, red), em = wg_sum(ex_m, red), ev = wg_sum(ex_v, red);
+  if (threadIdx.x == 0) {
+    sm_[0] = c0m; sm_[1] = n > 0 ? sqrt(qm / n) : NAN; sm_[2] = n; sm_[3] = em; sm_[4] = mean_m - c0m;
+    sm_[5] = (lo_m == hi_m) ? 1.0 : 0.0; sm_[6] = lo_m; sm_[7] = hi_m;
+    sv_[0] = c0v; sv_[1] = n > 0 ? sqrt(qv / n) : NAN; sv_[2] = n; sv_[3] = ev; sv_[4] = mean_v - c0v;
+    sv_[5] = (lo_v == hi_v) ? 1.0 : 0.0; sv_[6] = lo_v; sv_[7] = hi_v;
+  }
+}
+
+// coefficient rows of selected contrasts (for the host-side tail fits of the few tests that need them)
+__global__ __launch_bounds__(256) void k_contrast_rows(const double *__restrict__ ym, const double *__restrict__ yv, int64_t ld,
+                                                       int32_t num_boot, int32_t n_groups, int32_t ctrl,
+                                                       const int32_t *__restrict__ test_gene, const int32_t *__restrict__ test_grp,
+                                                       int32_t which, double *__restrict__ out) {
+  int64_t t = blockIdx.x;
+  int gene = test_gene[t], grp = test_grp[t];
+  const double *ma = ym + ((int64_t)gene * n_groups + grp) * ld, *mc = ym + ((int64_t)gene * n_groups + ctrl) * ld;
+  const double *va = yv + ((int64_t)gene * n_groups + grp) * ld, *vc = yv + ((int64_t)gene * n_groups + ctrl) * ld;
+  for (int c = threadIdx.x; c <= num_boot; c += 256) {
+    double a = ma[c], b = mc[c], p = va[c], q = vc[c];
+    bool ok = isfinite(a) && isfinite(b) && isfinite(p) && isfinite(q);
+    out[t * ld + c] = ok ? (which ? p - q : a - b) : NAN;
+  }
+}
+
 extern "C" {
 
 int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups,
@@ -337,6 +418,29 @@ int mm_cross_resampled(const double *d_yt, int64_t ld, int32_t num_boot, int32_t
   size_t shm = (size_t)n_groups * 20 + 8;
   hipLaunchKernelGGL(k_cross_resampled, dim3((unsigned)n_tests), dim3(K9_THREADS), shm, (hipStream_t)stream, d_yt, ld, num_boot, n_groups,
                      d_test_gene, d_tt, d_good, d_Nc, d_rep, d_bcol, seed, d_coef, d_stats, d_status);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_contrast_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups, int32_t ctrl,
+                      const int32_t *d_test_gene, const int32_t *d_test_grp, const uint8_t *d_good, int64_t n_tests,
+                      double *d_stats_mean, double *d_stats_var, void *stream) {
+  MM_ARG(d_ym && d_yv && d_test_gene && d_test_grp && d_good && d_stats_mean && d_stats_var);
+  MM_ARG(n_tests >= 0 && n_tests < 2147483647LL && n_groups > 0 && ctrl >= 0 && ctrl < n_groups && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_tests == 0) return MM_OK;
+  hipLaunchKernelGGL(k_contrast_stats, dim3((unsigned)n_tests), dim3(K9_THREADS), 0, (hipStream_t)stream, d_ym, d_yv, ld, num_boot, n_groups,
+                     ctrl, d_test_gene, d_test_grp, d_good, d_stats_mean, d_stats_var);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_contrast_rows(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups, int32_t ctrl,
+                     const int32_t *d_test_gene, const int32_t *d_test_grp, int64_t n_tests, int32_t which, double *d_out,
+                     void *stream) {
+  MM_ARG(d_ym && d_yv && d_test_gene && d_test_grp && d_out && n_tests >= 0 && n_tests < 2147483647LL && (which == 0 || which == 1));
+  if (n_tests == 0) return MM_OK;
+  hipLaunchKernelGGL(k_contrast_rows, dim3((unsigned)n_tests), dim3(256), 0, (hipStream_t)stream, d_ym, d_yv, ld, num_boot, n_groups, ctrl,
+                     d_test_gene, d_test_grp, which, d_out);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -446,6 +446,28 @@ class Bootstrap1D:
         return coef, host(stats)[:n_tests]
 
 
+    def contrast(self, test_gene, test_grp, ctrl, good):
+        """Two-group contrasts against the control group ``ctrl`` (mm_contrast_stats): returns (stats_mean, stats_var)
+        host arrays [n_tests][8]; ``rows(which, idx)`` gives the coefficient rows of selected tests on demand."""
+        torch = _torch()
+        n_tests = len(test_gene)
+        st_m = empty((max(1, n_tests), 8), torch.float64)
+        st_v = empty((max(1, n_tests), 8), torch.float64)
+        d_tg, d_gr = dev(np.asarray(test_gene, dtype=np.int32)), dev(np.asarray(test_grp, dtype=np.int32))
+        d_good = dev(np.asarray(good, dtype=np.uint8))
+        _lib.call("mm_contrast_stats", P(self.ym), P(self.yv), self.ld, self.B, self.ng, int(ctrl), P(d_tg), P(d_gr), P(d_good), n_tests,
+                  P(st_m), P(st_v), _stream())
+
+        def rows(which, idx):
+            idx = np.asarray(idx, dtype=np.int64)
+            out = empty((max(1, len(idx)), self.ld), torch.float64)
+            a, b = dev(np.asarray(test_gene, dtype=np.int32)[idx]), dev(np.asarray(test_grp, dtype=np.int32)[idx])
+            _lib.call("mm_contrast_rows", P(self.ym), P(self.yv), self.ld, self.B, self.ng, int(ctrl), P(a), P(b), len(idx), int(which),
+                      P(out), _stream())
+            return host(out)[: len(idx)]
+
+        return host(st_m)[:n_tests], host(st_v)[:n_tests], rows
+
     def contract_resampled(self, test_gene, tt, good, which, gene_mask, M, Nc, rep=None, bcol=None, seed=0):
         """resample_rep=True: residualise the response rows (copy), then the resampled weighted slopes + null statistics.
         ``rep``/``bcol`` [n_genes][n_groups][B] (int16/int32) replay np.random.choice; None -> drawn on the device."""

@@ -73,8 +73,42 @@ def get_pool(num_cpus):
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
 
+        if not _POOL:
+            import atexit
+
+            atexit.register(shutdown_pools)
         pool = _POOL[num_cpus] = ProcessPoolExecutor(max_workers=num_cpus, mp_context=mp.get_context("spawn"))
     return pool
+
+
+def shutdown_pools():
+    """Stop the tail-fit workers (also registered with atexit, so interpreter shutdown is clean)."""
+    for k in list(_POOL):
+        _POOL.pop(k).shutdown(wait=True, cancel_futures=True)
+
+
+class _main_hidden:
+    """While workers are being started, hide ``__main__``'s file/spec from multiprocessing's spawn preparation, so a user
+    script without an ``if __name__ == '__main__'`` guard is NOT re-executed in every worker (the workers only need this
+    module, which they import by name; re-running a script that opens the GPU would also multiply GPU processes)."""
+
+    def __enter__(self):
+        import sys
+
+        self.main = sys.modules.get("__main__")
+        self.saved = {}
+        for a in ("__file__", "__spec__"):
+            if self.main is not None and hasattr(self.main, a):
+                self.saved[a] = getattr(self.main, a)
+        if "__spec__" in self.saved:
+            self.main.__spec__ = None
+        if "__file__" in self.saved:
+            del self.main.__file__
+
+    def __exit__(self, *exc):
+        for a, v in self.saved.items():
+            setattr(self.main, a, v)
+        return False
 
 
 def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1):
@@ -99,7 +133,9 @@ def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1):
         rows = fetch_rows(need)
         jobs = [(rows[i], float(c[t])) for i, t in enumerate(need)]
         if num_cpus and num_cpus > 1 and len(jobs) > 1:
-            res = list(get_pool(num_cpus).map(_tail_job, jobs, chunksize=max(1, len(jobs) // (4 * num_cpus))))
+            with _main_hidden():        # workers are spawned on submit
+                it = get_pool(num_cpus).map(_tail_job, jobs, chunksize=max(1, len(jobs) // (4 * num_cpus)))
+            res = list(it)
         else:
             res = [tail_fit_asl(*j) for j in jobs]
         asl[need] = res

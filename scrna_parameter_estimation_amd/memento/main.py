@@ -537,6 +537,68 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         return adata
 
 
+def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', fill_seed=0, max_rows=None, approx=False):
+    """Perturb-seq style batch test: every group against one shared ``control`` group (a label of
+    ``adata.uns['memento']['groups']`` or its index), for all kept genes, in one call.
+
+    The reference handles this design with a Python loop over guides (subset to control + guide, create_groups,
+    compute_1d_moments, ht_1d_moments; e.g. analysis/sciplex/sciplex_dv.py:18-59), re-bootstrapping the control group
+    for every guide.  Here each (gene, group) is bootstrapped once and the two-group test statistic -- for the groups
+    {control, guide} with a binary treatment and an intercept, _regress_1d (hypothesis_test.py:269-291) reduces to
+    log-moment(guide) - log-moment(control) -- is taken for every guide from the shared control rows.  The moments,
+    gene filters and the mean-variance fit are those of ``compute_1d_moments`` over ALL groups (the per-guide loop refits
+    them on each two-group subset), so numbers differ from that loop by the fit, not by the test.
+
+    Returns a DataFrame (gene, group, de_coef, de_se, de_pval, dv_coef, dv_se, dv_pval) and stores the arrays in
+    ``uns['memento']['1d_ht_vs_control']``."""
+    m = adata.uns['memento']
+    st = m['_hip']
+    groups = m['groups']
+    ng = len(groups)
+    ctrl = groups.index(control) if not isinstance(control, (int, np.integer)) else int(control)
+    others = [j for j in range(ng) if j != ctrl]
+    mean_only = m['estimator_type'] == 'mean_only'
+    names = _var_names(adata)
+    gq = np.array([m['group_q'][g] for g in groups])
+    true_mean = np.stack([m['1d_moments'][g][0] for g in groups])
+    true_rv = np.stack([m['1d_moments'][g][2] for g in groups])
+    fit = m['mv_regressor'][groups[0]]
+    G_all = len(st.gene_idx)
+    if max_rows is None:
+        max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
+    chunk = max(1, int(max_rows) // max(1, ng))
+    cols = {k: [] for k in ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')}
+    for g0 in range(0, G_all, chunk):
+        g1 = min(G_all, g0 + chunk)
+        G = g1 - g0
+        bs = engine.Bootstrap1D(st.blocks, st.gene_idx[g0:g1], st.maxx, st.sf_bin, st.sf_table, gq, num_boot)
+        skip = _pair_skip(true_mean[:, g0:g1], true_rv[:, g0:g1])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            tm_log = np.where(skip, np.nan, np.log(true_mean[:, g0:g1].T.reshape(-1)))
+            tv_log = np.where(skip, np.nan, np.log(true_rv[:, g0:g1].T.reshape(-1)))
+        bs.alloc_outputs(tm_log, tv_log)
+        r1, r0 = np.zeros(bs.n_pairs), np.zeros(bs.n_pairs)
+        live = np.flatnonzero(~skip)
+        u = np.random.random(2 * len(live))
+        r1[live], r0[live] = u[0::2], u[1::2]
+        n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)
+        good = ((~skip) & (bs.K >= 2) & ~(n_inv < 0).any(axis=1)).reshape(G, ng)
+        test_gene = np.repeat(np.arange(G), len(others))
+        test_grp = np.tile(np.asarray(others), G)
+        st_m, st_v, rows = bs.contrast(test_gene, test_grp, ctrl, good)
+        for tag, stt, which in (('mean', st_m, 0), ('var', st_v, 1)):
+            p = _asl.asl_from_stats(stt, approx, lambda idx, w=which: rows(w, idx), num_cpus)
+            cols[tag + '_coef'].append(stt[:, 0])
+            cols[tag + '_se'].append(stt[:, 1])
+            cols[tag + '_asl'].append(p)
+    out = {k: (np.concatenate(v) if v else np.zeros(0)) for k, v in cols.items()}
+    m['1d_ht_vs_control'] = dict(out, control=groups[ctrl], groups=[groups[j] for j in others])
+    df = pd.DataFrame({'gene': np.repeat(names, len(others)), 'group': np.tile([groups[j] for j in others], G_all)})
+    df['de_coef'], df['de_se'], df['de_pval'] = out['mean_coef'], out['mean_se'], out['mean_asl']
+    df['dv_coef'], df['dv_se'], df['dv_pval'] = out['var_coef'], out['var_se'], out['var_asl']
+    return df
+
+
 # ----------------------------------------------------------------------------------------------
 # 2D: compute_2d_moments / ht_2d_moments / get_corr_matrix
 # ----------------------------------------------------------------------------------------------

@@ -214,3 +214,27 @@ def test_public_api_names_match_reference():
         assert got[: len(params)] == params, (name, got)
     assert inspect.signature(memento.ht_1d_moments).parameters["num_boot"].default == 10000
     assert inspect.signature(memento.setup_memento).parameters["filter_mean_thresh"].default == 0.07
+
+
+def test_tail_fit_pool_does_not_rerun_unguarded_main(tmp_path):
+    """The tail-fit workers must not re-execute a user script that has no __main__ guard (spawn would, by default)."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "unguarded.py"
+    script.write_text(
+        "import sys, os\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "print('MAIN EXECUTED', flush=True)\n"
+        "import numpy as np\n"
+        "from scrna_parameter_estimation_amd.memento import asl\n"
+        "rng = np.random.default_rng(0)\n"
+        "B = 600\n"
+        "st = np.zeros((4, 8)); rows = rng.normal(size=(4, B + 1)); rows[:, 0] = 0.5\n"
+        "st[:, 0] = 0.5; st[:, 1] = 1.0; st[:, 2] = B; st[:, 3] = 3\n"
+        "p = asl.asl_from_stats(st, False, lambda idx: rows[idx], num_cpus=2)\n"
+        "assert np.isfinite(p).all()\n"
+        "print('DONE', flush=True)\n")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("MAIN EXECUTED") == 1 and "DONE" in out.stdout

@@ -233,6 +233,47 @@ def test_ht_1d_rich_design_and_treatment_for_gene(api_approx):
     assert len(df) == len(g["httfg_mean_coef"]) and list(df["tx"][:4]) == ["cond", "dose", "cond", "dose"]
 
 
+def test_ht_1d_vs_control_equals_two_group_regression(api_small):
+    """Batched guide-vs-control contrasts: each contrast equals the reference's two-group regression
+    (_regress_1d with covariate = intercept, treatment = guide indicator) applied to the same replicate rows."""
+    from oracle import memento_oracle as orc
+    from scrna_parameter_estimation_amd import engine
+
+    g = api_small
+    memento, adata = _run_to_moments(g)
+    m = adata.uns["memento"]
+    ng = len(m["groups"])
+    np.random.seed(3)
+    df = memento.ht_1d_vs_control(adata, control=m["groups"][1], num_boot=250, num_cpus=1, approx=True, max_rows=80)
+    assert len(df) == len(g["gene_list"]) * (ng - 1) and list(df.columns[:2]) == ["gene", "group"]
+    # recompute on the last gene chunk straight from the resident replicate rows
+    np.random.seed(3)
+    df1 = memento.ht_1d_vs_control(adata, control=1, num_boot=250, num_cpus=1, approx=True)       # one chunk
+    np.testing.assert_allclose(df1["de_coef"].values, df["de_coef"].values, rtol=1e-12, equal_nan=True)
+    # (one chunk: all genes are still resident)
+    st = m["_hip"]
+    np.random.seed(3)
+    bs = engine.Bootstrap1D(st.blocks, st.gene_idx, st.maxx, st.sf_bin, st.sf_table, np.array([m["group_q"][k] for k in m["groups"]]), 250)
+    tm = np.stack([m["1d_moments"][k][0] for k in m["groups"]]).T.reshape(-1)
+    tv = np.stack([m["1d_moments"][k][2] for k in m["groups"]]).T.reshape(-1)
+    skip = ~(np.isfinite(np.log(tm)) & np.isfinite(np.log(tv)))
+    bs.alloc_outputs(np.log(tm), np.log(tv))
+    u = np.random.random(2 * int((~skip).sum()))
+    r1, r0 = np.zeros(bs.n_pairs), np.zeros(bs.n_pairs)
+    r1[~skip], r0[~skip] = u[0::2], u[1::2]
+    bs.run(skip, r1, r0, m["mv_regressor"]["all"], fill_mode=0, fill_seed=0)
+    ym, yv = engine.host(bs.ym), engine.host(bs.yv)
+    Nc = np.array([m["group_cells"][k].shape[0] for k in m["groups"]], dtype=float)
+    others = [j for j in range(ng) if j != 1]
+    for gi in range(0, len(g["gene_list"]), 7):
+        for oi, j in enumerate(others):
+            rows = [gi * ng + 1, gi * ng + j]
+            ref = orc.regress_1d(np.ones((2, 1)), np.array([[0.0], [1.0]]), ym[rows], yv[rows], Nc[[1, j]], resampling="bootstrap", approx=True)
+            r = df1.iloc[gi * (ng - 1) + oi]
+            np.testing.assert_allclose([r.de_coef, r.de_se, r.de_pval, r.dv_coef, r.dv_se, r.dv_pval],
+                                       [ref[0][0], ref[1][0], ref[2][0], ref[3][0], ref[4][0], ref[5][0]], rtol=1e-7, atol=1e-12)
+
+
 def test_inplace_false_and_prepare_to_save(api_small):
     """inplace=False returns a copy and leaves the input untouched; prepare_to_save drops everything that cannot be
     written to disk (device handles, per-group regressors) -- reference: main.py:39-40, :673-683."""
