@@ -129,6 +129,11 @@ int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t
                   const double *d_grp_ncells /* [n_groups] */, double *d_pk, double *d_lq, double *d_v, double *d_a, double *d_b,
                   int32_t *d_status, void *stream);
 
+/* Profiling hook (no reference counterpart): when d_buf != NULL, every later mm_boot1d_replay launch writes, per tile
+ * (wave), {start, end (100 MHz wall clock), HW_ID, XCC_ID} into d_buf[tile*4 .. tile*4+3]; d_buf must hold 4*n_tiles
+ * int64.  Pass NULL to switch it off.  Process-global; used by tools/replay_balance.py only. */
+int mm_debug_wave_clock(int64_t *d_buf);
+
 /* ---- K6+K7: replay bootstrap -- numpy Generator(PCG64).multinomial draw-for-draw + replicate moments
  * replaces bootstrap._bootstrap_1d  memento/bootstrap.py:97-110 and the tuple branch of
  * estimator._hyper_1d_relative  memento/estimator.py:171-174, :182-183.

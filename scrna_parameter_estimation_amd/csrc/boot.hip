@@ -17,6 +17,9 @@
 #ifndef BOOT_MIN_WAVES
 #define BOOT_MIN_WAVES 1
 #endif
+#ifndef BOOT_SETPRIO
+#define BOOT_SETPRIO 2
+#endif
 __global__ __launch_bounds__(256, BOOT_MIN_WAVES) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v, const double *__restrict__ a,
                                                        const double *__restrict__ b,
@@ -25,10 +28,15 @@ __global__ __launch_bounds__(256, BOOT_MIN_WAVES) void k_boot1d_replay(const dou
                                                        const double *__restrict__ slot_omq, const int64_t *__restrict__ slot_row, uint64_t st0, uint64_t st1,
                                                        uint64_t st2, uint64_t st3, int32_t num_boot, int32_t mean_only,
                                                        int64_t ld, double *__restrict__ out_mean, double *__restrict__ out_var,
-                                                       int32_t *__restrict__ w_dump, int32_t kmax_dump) {
+                                                       int32_t *__restrict__ w_dump, int32_t kmax_dump,
+                                                       int64_t *__restrict__ wave_clock) {
   int lane = mm_lane();
   int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (tile >= n_tiles) return;
+  int64_t t_start = wave_clock ? (int64_t)wall_clock64() : 0;
+  // Two waves share a SIMD.  The host puts the long tiles in the first half of the grid (engine.pair_tiles) and pairs
+  // each with a short one from the second half: the long tile is the critical path, so it is served first.
+  if (tile * 2 < n_tiles) __builtin_amdgcn_s_setprio(BOOT_SETPRIO);
   int64_t slot = tile * 64 + lane;
   int K = slot_K[slot];
   int64_t row = slot_row[slot];
@@ -91,6 +99,12 @@ __global__ __launch_bounds__(256, BOOT_MIN_WAVES) void k_boot1d_replay(const dou
       om[r] = mean;
       ov[r] = var;
     }
+  }
+  if (wave_clock && lane == 0) {  // profiling hook (mm_debug_wave_clock): when and where this wave ran
+    wave_clock[tile * 4 + 0] = t_start;
+    wave_clock[tile * 4 + 1] = (int64_t)wall_clock64();
+    wave_clock[tile * 4 + 2] = (int64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: se / cu / simd / wave slot
+    wave_clock[tile * 4 + 3] = (int64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
   }
 }
 
@@ -254,6 +268,7 @@ __global__ __launch_bounds__(256) void k_boot2d_replay(const double *__restrict_
   int lane = mm_lane();
   int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (tile >= n_tiles) return;
+  if (tile * 2 < n_tiles) __builtin_amdgcn_s_setprio(BOOT_SETPRIO);  // long tiles first, see k_boot1d_replay
   int64_t slot = tile * 64 + lane;
   int K = slot_K[slot];
   int64_t row = slot_row[slot];
@@ -312,7 +327,14 @@ __global__ __launch_bounds__(256) void k_boot2d_replay(const double *__restrict_
   }
 }
 
+static int64_t *g_wave_clock = nullptr;  // set by mm_debug_wave_clock; nullptr = no profiling writes
+
 extern "C" {
+
+int mm_debug_wave_clock(int64_t *d_buf) {
+  g_wave_clock = d_buf;
+  return MM_OK;
+}
 
 int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
                      const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
@@ -322,10 +344,11 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
   MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   MM_ARG(d_out_mean && d_out_var && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
-  int64_t blocks = (n_tiles + 3) / 4;
-  hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
+  MM_ARG(n_tiles < 2147483647LL);
+  // 4 tiles per 256-thread workgroup: tiles t and t + 1024 (+-3) then meet on one SIMD, which engine.pair_tiles relies on
+  hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
-                     pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump);
+                     pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -349,8 +372,7 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
   MM_ARG(d_pk && d_lq && d_v1 && d_v2 && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   MM_ARG(d_out_corr && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
-  int64_t blocks = (n_tiles + 3) / 4;
-  hipLaunchKernelGGL(k_boot2d_replay, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
+  hipLaunchKernelGGL(k_boot2d_replay, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, ld, d_out_corr);
   MM_LAUNCH_CHECK();

@@ -18,11 +18,17 @@ MAX_COUNT = (1 << 19) - 1
 ORDER_SMALL_CAP = 1024
 ORDER_BIG_CAP = 8192
 ORDER_BIG_CAP_2D = 4096
-# lane-packing cost model of the replay kernel (instructions per bin step: C0 + C1 * active lanes)
-PACK_C0 = float(os.environ.get('MM_PACK_C0', 250))
-PACK_C1 = float(os.environ.get('MM_PACK_C1', 4))
-# ~2 waves on each of the 1024 SIMDs: measured optimum on C2 and C3 (profiles/README.md); fewer idles SIMDs, more adds a partial round
+# Lane packing of the replay kernel.  (a) tile widths: every tile gets the same budget K_max * (C0 + C1 * lanes), the budget
+# is set so that about PACK_WAVES tiles come out (2 per SIMD, never more than 2048: a third wave on a SIMD is a second round);
+# C0/C1/PACK_WAVES were tuned on the hardware together with the pairing order below (profiles/README.md).
+PACK_C0 = float(os.environ.get('MM_PACK_C0', 220))
+PACK_C1 = float(os.environ.get('MM_PACK_C1', 3))
 PACK_WAVES = int(os.environ.get('MM_PACK_WAVES', 2000))
+# (b) measured time of one bin step of a wave of L chains running as the OLDER wave of its SIMD, us (tools/replay_balance.py,
+# C3): used to rank tiles by length for the dispatch order (pair_tiles)
+_PACK_L = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 56, 64)
+_PACK_US = (1.34, 1.91, 2.35, 2.60, 2.86, 3.13, 3.29, 3.51, 3.88, 4.18, 4.40, 4.58, 4.70, 4.80, 5.25, 5.68, 6.08, 6.44, 6.7, 7.0, 7.25, 7.7, 8.1)
+PACK_COST = np.interp(np.arange(1, 65), _PACK_L, _PACK_US)
 
 
 def _torch():
@@ -228,31 +234,7 @@ class CountBlocks:
         return host(out_S), host(out_sx, np.uint64), host(out_mx, np.uint32)
 
 
-def pack_lanes(K_sorted_desc, target_waves):
-    """Lane packing of sequential chains into 64-wide tiles.  ``K_sorted_desc``: steps of each chain, descending.
-
-    A chain is one sequential stream, so a wave costs about  K_max(lanes) x c(L)  with c(L) = C0 + C1*L
-    instructions per bin step (lanes diverge between the inversion and BTPE samplers).  Wide waves are the most
-    instruction-efficient, but the heaviest chain bounds the makespan; so every wave gets the same cost budget:
-    L(K) = largest lane count with K*c(L) <= budget, and the budget is chosen (bisection) to yield about
-    ``target_waves`` waves.  Returns (slot of every chain = tile*64 + lane, number of tiles)."""
-    Ks = np.asarray(K_sorted_desc, dtype=np.float64)
-    n_act = len(Ks)
-    if n_act == 0:
-        return np.zeros(0, dtype=np.int64), 0
-    C0, C1 = PACK_C0, PACK_C1
-
-    def lanes_for(budget):
-        return np.clip(np.floor((budget / np.maximum(Ks, 1.0) - C0) / C1), 1, 64)
-
-    lo_b, hi_b = C0 + C1, float(Ks.max()) * (C0 + 64 * C1) * 4.0
-    for _ in range(50):
-        mid = 0.5 * (lo_b + hi_b)
-        if (1.0 / lanes_for(mid)).sum() > target_waves:
-            lo_b = mid
-        else:
-            hi_b = mid
-    lanes = np.maximum.accumulate(lanes_for(hi_b).astype(np.int64))    # non-decreasing along the K-descending order
+def _tiles_from_lanes(lanes, n_act):
     slot_of = np.zeros(n_act, dtype=np.int64)
     n_tiles, pos = 0, 0
     while pos < n_act:
@@ -264,6 +246,62 @@ def pack_lanes(K_sorted_desc, target_waves):
         n_tiles += -(-cnt // L)
         pos = run_end
     return slot_of, n_tiles
+
+
+def pack_lanes(K_sorted_desc, target_waves, dense=False):
+    """Lane packing of sequential chains into 64-wide tiles (one tile = one wave).
+
+    ``K_sorted_desc``: steps of each chain, descending.  A chain is one sequential stream, so a wave costs about
+    K_max(lanes) x c(L), c(L) = C0 + C1*L per bin step (lanes diverge between the inversion and BTPE samplers and every
+    data-dependent loop runs for the slowest lane).  Wide waves are the most instruction-efficient, but the heaviest chain
+    bounds the makespan; so every wave gets the same cost budget: L(K) = largest lane count with K*c(L) <= budget, and the
+    budget is chosen (bisection) to yield about ``target_waves`` waves.  ``dense``: plain 64-wide tiles (fast mode: one
+    wave per chain, lanes = replicates).  Returns (slot of every chain = tile*64 + lane, number of tiles)."""
+    Ks = np.maximum(np.asarray(K_sorted_desc, dtype=np.float64), 1.0)
+    n_act = len(Ks)
+    if n_act == 0:
+        return np.zeros(0, dtype=np.int64), 0
+    if dense:
+        return _tiles_from_lanes(np.full(n_act, 64, dtype=np.int64), n_act)
+    C0, C1 = PACK_C0, PACK_C1
+
+    def lanes_for(budget):
+        return np.clip(np.floor((budget / Ks - C0) / C1), 1, 64)
+
+    lo_b, hi_b = C0 + C1, float(Ks.max()) * (C0 + 64 * C1) * 4.0
+    for _ in range(50):
+        mid = 0.5 * (lo_b + hi_b)
+        if (1.0 / lanes_for(mid)).sum() > target_waves:
+            lo_b = mid
+        else:
+            hi_b = mid
+    return _tiles_from_lanes(np.maximum.accumulate(lanes_for(hi_b).astype(np.int64)), n_act)
+
+
+PAIR_SLOTS = int(os.environ.get("MM_PAIR_SLOTS", 1024))      # SIMDs: tiles t and t + PAIR_SLOTS share one
+
+
+def pair_tiles(slot_of, n_tiles, K_of):
+    """Dispatch order of the replay tiles.  Two waves share a SIMD and the OLDER one is served first (measured: the
+    younger wave runs at ~0.46 of its lone speed until the older retires, tools/replay_balance.py).  Workgroups are handed
+    out round-robin, so tile t and tile t + 1024 meet on one SIMD: put the 1024 longest tiles first, longest first, and
+    behind them the next 1024 in ASCENDING length -- the longest tile then shares its SIMD with the shortest partner
+    instead of one of its own size; anything beyond 2048 follows longest-first and refills slots as they free up."""
+    if os.environ.get("MM_PAIR_TILES", "1") == "0" or n_tiles <= 2:
+        return slot_of
+    tile = slot_of // 64
+    lanes = np.bincount(tile, minlength=n_tiles)
+    kmax = np.zeros(n_tiles)
+    np.maximum.at(kmax, tile, np.asarray(K_of, dtype=np.float64))
+    est = kmax * PACK_COST[np.clip(lanes, 1, 64) - 1]
+    by_len = np.argsort(-est, kind="stable")
+    h = min(PAIR_SLOTS, n_tiles // 2 + n_tiles % 2)
+    first, rest = by_len[:h], by_len[h:]
+    second, tail = rest[:h][::-1], rest[h:]
+    new_order = np.concatenate([first, second, tail])
+    new_id = np.empty(n_tiles, dtype=np.int64)
+    new_id[new_order] = np.arange(n_tiles)
+    return new_id[tile] * 64 + slot_of % 64
 
 
 def pcg64_state(seed=5):
@@ -375,7 +413,9 @@ class Bootstrap1D:
         order = act[np.argsort(-self.K[act], kind="stable")]
         n_act = len(order)
         # replay: cost-model lane packing (one lane = one sequential chain); fast: dense 64-wide tiles (one WAVE per pair)
-        slot_of, n_tiles = pack_lanes(self.K[order], 1 if fast else target_waves)
+        slot_of, n_tiles = pack_lanes(self.K[order], target_waves, dense=fast)
+        if not fast:
+            slot_of = pair_tiles(slot_of, n_tiles, self.K[order])
         self.n_tiles = n_tiles
         pair_slot = np.full(self.n_pairs, -1, dtype=np.int64)
         pair_slot[order] = slot_of
@@ -411,6 +451,7 @@ class Bootstrap1D:
         self.w_dump = zeros((n_tiles * 64, kmax_dump, B), torch.int32) if dump_weights else None
         self.kmax_dump = kmax_dump
         self.slot_pair, self.slot_K, self.pair_slot, self.tile_ptr = slot_pair, slot_K, pair_slot, tile_ptr
+        self._ops, self._nobs = ops, nobs          # kept for diagnostics (tools/replay_balance.py)
         d_slot_K, d_nobs, d_omq, d_slot_pair = dev(slot_K), dev(nobs), dev(omq), dev(slot_pair)
         if n_tiles and fast:
             _lib.call("mm_boot1d_fast", *[P(o) for o in ops], P(d_tile_ptr), n_tiles * 64, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
@@ -612,6 +653,7 @@ class Bootstrap2D:
             raise NotImplementedError(f"a (pair, group) has more than {ORDER_BIG_CAP_2D} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         slot_of, n_tiles = pack_lanes(self.K[order], target_waves)
+        slot_of = pair_tiles(slot_of, n_tiles, self.K[order])
         pair_slot = np.full(self.n_q, -1, dtype=np.int64)
         pair_slot[order] = slot_of
         slot_pair = np.full(n_tiles * 64, -1, dtype=np.int64)
