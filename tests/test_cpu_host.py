@@ -238,3 +238,37 @@ def test_tail_fit_pool_does_not_rerun_unguarded_main(tmp_path):
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.count("MAIN EXECUTED") == 1 and "DONE" in out.stdout
+
+
+def test_pack_and_pair_tiles_are_a_valid_schedule():
+    """Lane packing + dispatch order: every chain gets exactly one (tile, lane) slot, tiles hold chains of similar length,
+    the first half of the grid holds the longest tiles (longest first) and the second half pairs them with the shortest."""
+    from scrna_parameter_estimation_amd import engine
+
+    rng = np.random.default_rng(0)
+    K = np.sort(rng.integers(2, 400, size=50_000))[::-1]
+    slot, nt = engine.pack_lanes(K, engine.PACK_WAVES)
+    assert nt <= 2048 and len(np.unique(slot)) == len(K) and slot.max() < nt * 64
+    slot2 = engine.pair_tiles(slot, nt, K)
+    assert len(np.unique(slot2)) == len(K) and slot2.max() < nt * 64
+    # same tiles, only renumbered: chains that shared a tile still do, lanes unchanged
+    assert (slot2 % 64 == slot % 64).all()
+    same_before = slot[:-1] // 64 == slot[1:] // 64
+    same_after = slot2[:-1] // 64 == slot2[1:] // 64
+    assert (same_before == same_after).all()
+    tile = slot2 // 64
+    lanes = np.bincount(tile, minlength=nt)
+    kmax = np.zeros(nt)
+    np.maximum.at(kmax, tile, K)
+    est = kmax * engine.PACK_COST[lanes - 1]
+    h = nt // 2 + nt % 2
+    assert (np.diff(est[:h]) <= 1e-9).all()            # first half: longest first
+    assert (np.diff(est[h:2 * h]) >= -1e-9).all()      # second half: ascending, so tile t meets a short partner at t + h
+    assert est[:h].min() >= est[h:].max() - 1e-9
+    # degenerate inputs
+    assert engine.pack_lanes(np.zeros(0), 2000) [1] == 0
+    s1, n1 = engine.pack_lanes(np.array([7]), 2000)
+    assert n1 == 1 and engine.pair_tiles(s1, n1, np.array([7])).tolist() == [0]
+    # fast mode: dense 64-wide tiles
+    sd, nd = engine.pack_lanes(K[:1000], 2000, dense=True)
+    assert nd == 16 and (np.bincount(sd // 64)[:15] == 64).all()
