@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--config", default=os.environ.get("MM_BENCH_CONFIG", "C3"), choices=list(CONFIGS))
     ap.add_argument("--num-cpus", type=int, default=0, help="host processes for the tail fits (default: min(16, cores / ranks))")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-baseline-cores", type=int, default=max(1, min(16, os.cpu_count() or 1)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -271,45 +272,87 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch):
-    """The CPU oracle (numpy restatement pinned to the reference) on a bounded sample of genes, 1 core."""
+_CPU = {}
+
+
+def _cpu_init(shared):
+    """Pool initializer: static inputs of the CPU baseline (group membership, size factors, design) arrive once."""
+    sys.path.insert(0, ROOT)
+    _CPU.update(shared)
+
+
+def _cpu_gene(job):
+    """One gene of the CPU baseline: its share of the moments pass + the oracle's _ht_1d (bootstrap, regression, ASL)."""
     from oracle import memento_oracle as orc
 
+    col32, tm_g, trv_g, seed = job
+    c = _CPU
+    col = col32.astype(np.float64)
+    np.random.seed(seed)
+    t0 = time.time()
+    for k in range(len(c["sel"])):          # moments part of the step for this gene (estimator.py:177-183)
+        x = col[c["sel"][k]]
+        w = 1.0 / c["sf"][c["sel"][k]]
+        _ = ((x * w).sum(), (x * x * w * w).sum(), (x * w * w).sum())
+    orc.ht_1d_gene(tm_g, trv_g, [col[s] for s in c["sel"]], c["asf"], c["cov"], c["trt"], c["Nc"], c["num_boot"], c["fit"], c["gq"],
+                   resampling="bootstrap", approx=False)
+    return time.time() - t0
+
+
+def cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch):
+    """The CPU oracle (numpy restatement pinned to the reference) on a bounded sample of genes of the same matrix:
+    ``--cpu-baseline-cores`` worker processes (default: the host cores of one GPU's share, at most 16), one gene per task,
+    for about ``--cpu-baseline-seconds`` of wall time."""
     m = adata.uns["memento"]
     groups = m["groups"]
     ng = len(groups)
     kept = state.gene_idx
-    n_try = 64
+    cores = max(1, args.cpu_baseline_cores)
+    n_try = min(len(kept), max(8 * cores, int(1.5e9 / (8 * adata.shape[0]))))      # dense sample columns: <= ~1.5 GB of host memory
     pick = kept[:: max(1, len(kept) // n_try)][:n_try]
-    cols = sample_columns(csr, pick, torch)
+    cols = sample_columns(csr, pick, torch).astype(np.float32)
     gid = state.group_id
     sel = [np.flatnonzero(gid == k) for k in range(ng)]
-    sf = adata.obs["memento_size_factor"].values
-    asf = [m["all_approx_size_factor"][s] for s in sel]
-    gq = np.array([m["group_q"][g] for g in groups])
-    Nc = np.array([len(s) for s in sel], dtype=float)
     slot = {g: i for i, g in enumerate(kept)}
     tm = np.stack([m["1d_moments"][g][0] for g in groups])
     trv = np.stack([m["1d_moments"][g][2] for g in groups])
-    fit = m["mv_regressor"]["all"]
-    np.random.seed(0)
-    t0 = time.time()
-    done = 0
-    for j, g in enumerate(pick):
-        col = cols[:, j]
-        # moments part of the step for this gene (estimator.py:177-183)
-        for k in range(ng):
-            x = col[sel[k]]
-            w = 1.0 / sf[sel[k]]
-            _ = ((x * w).sum(), (x * x * w * w).sum(), (x * w * w).sum())
-        orc.ht_1d_gene(tm[:, slot[g]], trv[:, slot[g]], [col[s] for s in sel], asf, cov.values, trt.values, Nc,
-                       cfg["num_boot"], fit, gq, resampling="bootstrap", approx=False)
-        done += 1
-        if time.time() - t0 > args.cpu_baseline_seconds:
-            break
-    dt = time.time() - t0
-    return {"value": round(done * trt.shape[1] / dt, 4), "unit": "gene-tests/s", "cores": 1, "kind": "port",
-            "sample": f"{done} genes x {ng} groups x {cfg['num_boot']} bootstraps of the same matrix, oracle/memento_oracle.py, {dt:.1f} s"}
+    shared = dict(sel=sel, sf=adata.obs["memento_size_factor"].values, asf=[m["all_approx_size_factor"][s] for s in sel],
+                  gq=np.array([m["group_q"][g] for g in groups]), Nc=np.array([len(s) for s in sel], dtype=float), cov=cov.values,
+                  trt=trt.values, num_boot=cfg["num_boot"], fit=m["mv_regressor"]["all"])
+    jobs = [(np.ascontiguousarray(cols[:, j]), tm[:, slot[g]], trv[:, slot[g]], 1000 + j) for j, g in enumerate(pick)]
+    done, busy = 0, 0.0
+    if cores == 1:
+        _cpu_init(shared)
+        t0 = time.time()
+        for job in jobs:
+            busy += _cpu_gene(job)
+            done += 1
+            if time.time() - t0 > args.cpu_baseline_seconds:
+                break
+        dt = time.time() - t0
+    else:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor, wait, FIRST_COMPLETED
+
+        with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn"), initializer=_cpu_init, initargs=(shared,)) as ex:
+            list(ex.map(int, range(4 * cores)))                 # start all workers (imports, shared data) outside the timed region
+            t0 = time.time()
+            it = iter(jobs)
+            pending = {ex.submit(_cpu_gene, j) for j in [next(it) for _ in range(min(cores, len(jobs)))]}
+            while pending:
+                fin, pending = wait(pending, return_when=FIRST_COMPLETED)
+                for f in fin:
+                    busy += f.result()
+                    done += 1
+                    if time.time() - t0 < args.cpu_baseline_seconds:      # keep every worker busy until the budget is spent
+                        nxt = next(it, None)
+                        if nxt is not None:
+                            pending.add(ex.submit(_cpu_gene, nxt))
+            dt = time.time() - t0
+    return {"value": round(done * trt.shape[1] / dt, 4), "unit": "gene-tests/s", "cores": cores, "kind": "port",
+            "per_core": round(done * trt.shape[1] / max(busy, 1e-9), 4),
+            "sample": f"{done} genes x {ng} groups x {cfg['num_boot']} bootstraps of the same matrix, oracle/memento_oracle.py, "
+                      f"{cores} worker processes, {dt:.1f} s wall"}
 
 
 if __name__ == "__main__":
