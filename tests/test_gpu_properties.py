@@ -1,5 +1,6 @@
-"""Size-independent properties of the HIP path at a BASELINE-sized problem (config C2 shape: 100k cells x 20k
-genes, 5 % nnz, 8 groups), where the oracle would take too long: invariants the domain offers."""
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes -- configs[1] (C2: 100k cells x 20k genes,
+5 % nnz, 8 groups) and configs[2], the shape the metric is quoted on (C3: 1M cells x 20k genes, 3 % nnz, 20 groups) -- where
+the oracle would take too long: invariants the domain offers."""
 
 import numpy as np
 import pytest
@@ -7,20 +8,26 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def big():
+@pytest.fixture(scope="module", params=["C2", "C3"])
+def big(request):
+    import gc
+
     import torch
 
     import bench
     from scrna_parameter_estimation_amd import engine
 
-    cfg = dict(bench.CONFIGS["C2"])
+    cfg = dict(bench.CONFIGS[request.param])
+    ng = cfg["n_cond"] * cfg["n_rep"]
     csr = bench.synth_device_csr(cfg, 77, torch)
     rng = np.random.default_rng(5)
-    gid = rng.integers(-1, 8, size=cfg["cells"]).astype(np.int32)
-    blocks = engine.CountBlocks(csr, gid, 8)
+    gid = rng.integers(-1, ng, size=cfg["cells"]).astype(np.int32)          # -1: cells outside every group
+    blocks = engine.CountBlocks(csr, gid, ng)
     sf = rng.lognormal(0, 0.3, size=cfg["cells"])
-    return engine, torch, csr, gid, blocks, sf
+    yield engine, torch, csr, gid, blocks, sf
+    del csr, blocks
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def test_ingest_conserves_counts(big):
@@ -68,14 +75,15 @@ def test_histograms_and_multinomial_invariants(big):
     sf_bin = rng.integers(0, n_bins, size=csr.shape[0]).astype(np.uint8)
     sf_table = np.linspace(0.4, 2.5, n_bins)
     B = 64
-    bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(8, 0.07), B)
+    ng = blocks.n_groups
+    bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(ng, 0.07), B)
     Nc = blocks.grp_ncells
     for p in rng.choice(bs.n_pairs, size=40, replace=False):
         bi, xi, mu = bs.bins_of_pair(int(p))
-        g = int(p % 8)
+        g = int(p % ng)
         assert mu.sum() == Nc[g]                                           # bins partition the group's cells
-        assert (mu[xi > 0] * xi[xi > 0]).sum() == sumx[g, genes[p // 8]]   # and carry the gene's total count
-        assert xi.max() == maxx[g, genes[p // 8]]
+        assert (mu[xi > 0] * xi[xi > 0]).sum() == sumx[g, genes[p // ng]]  # and carry the gene's total count
+        assert xi.max() == maxx[g, genes[p // ng]]
     r = rng.random((2, bs.n_pairs))
     zeros = np.zeros(bs.n_pairs)
     bs.alloc_outputs(zeros, zeros)
@@ -83,7 +91,7 @@ def test_histograms_and_multinomial_invariants(big):
     w = bs.w_dump                                                          # [slot][k][B] int32 on device
     tot = w.sum(dim=1).cpu().numpy()                                       # multinomial weights of every replicate sum to N_g
     act = np.flatnonzero(bs.slot_pair >= 0)
-    want = Nc[bs.slot_pair[act] % 8]
+    want = Nc[bs.slot_pair[act] % ng]
     assert (tot[act] == want[:, None]).all()
     assert (w >= 0).all().item()
     # replicate means are non-negative and finite; bootstrap mean of the replicate means is close to the estimate
@@ -92,7 +100,7 @@ def test_histograms_and_multinomial_invariants(big):
 
 
 def test_replay_weights_bit_exact_at_scale(big):
-    """BTPE-heavy stress of the margin-guarded samplers on the device: ~2e6 draws on 12k-cell groups must equal
+    """BTPE-heavy stress of the samplers on the device: >1e6 draws on 12k-cell (C2) / 48k-cell (C3) groups must equal
     numpy's Generator(PCG64(5)).multinomial draw for draw."""
     engine, torch, csr, gid, blocks, sf = big
     S, sumx, maxx = blocks.moments(1.0 / sf)
@@ -103,7 +111,8 @@ def test_replay_weights_bit_exact_at_scale(big):
     sf_bin = rng.integers(0, n_bins, size=csr.shape[0]).astype(np.uint8)
     sf_table = np.linspace(0.4, 2.5, n_bins)
     B = 96
-    bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(8, 0.07), B)
+    ng = blocks.n_groups
+    bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(ng, 0.07), B)
     r = rng.random((2, bs.n_pairs))
     zeros = np.zeros(bs.n_pairs)
     bs.alloc_outputs(zeros, zeros)
@@ -115,7 +124,7 @@ def test_replay_weights_bit_exact_at_scale(big):
         code = xi.astype(np.float64) * r[0][p] + r[1][p] * sf_table[bi]
         o = np.argsort(code, kind="stable")
         mult = mu[o].astype(np.int64)
-        want = np.random.Generator(np.random.PCG64(5)).multinomial(int(blocks.grp_ncells[p % 8]), mult / mult.sum(), size=B).T
+        want = np.random.Generator(np.random.PCG64(5)).multinomial(int(blocks.grp_ncells[p % ng]), mult / mult.sum(), size=B).T
         np.testing.assert_array_equal(wd[bs.pair_slot[p], :len(mult), :], want, err_msg=f"pair {p}")
         n_draws += (len(mult) - 1) * B
     assert n_draws > 1_000_000
