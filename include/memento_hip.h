@@ -176,7 +176,10 @@ int mm_boot_fill_log(double *d_mean, double *d_var, int64_t n_rows, int64_t ld, 
  * good groups (d_good[gene][j] != 0); replicate b is dropped if any good row is non-finite in either
  * d_ym or d_yv (valid_boostrap_iters).  which = 0 uses d_ym, 1 uses d_yv as the response.
  * d_coef[t][ld] receives the coefficient row (NaN where dropped); d_stats[t][8] =
- *   {coef0, se (nanstd, ddof 0), n_valid_null, extreme_count, null_mean, all_equal, min, max}. */
+ *   {coef0, se (nanstd, ddof 0), n_valid_null, extreme_count, null_mean, all_equal, extreme_count_raw, range}:
+ *   extreme_count / null_mean are those of null = coef[1:] - coef[0] (resampling == 'bootstrap', :66-68),
+ *   extreme_count_raw counts |coef[b]| > |coef0| on the un-centred replicates (any other resampling value, :69-70; their
+ *   mean is null_mean + coef0); range = max - min over all columns. */
 int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups,
                       const int32_t *d_test_gene, const double *d_W /* [n_tests][n_groups] */, const uint8_t *d_good /* [n_genes][n_groups] */,
                       int64_t n_tests, int32_t which, double *d_coef, double *d_stats, void *stream);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(K9_THREADS) void k_contract_stats(const double *__r
   double mean1 = cnt > 0 ? tot / cnt : NAN;
   double a0 = fabs(c0);
   // pass B: variance about the mean of coef[1:], extreme count of null = coef[1:] - coef[0]
-  double s_sq = 0.0, s_ext = 0.0;
+  double s_sq = 0.0, s_ext = 0.0, s_raw = 0.0;
   for (int c = 1 + threadIdx.x; c < n_cols; c += K9_THREADS) {
     double val = crow[c];
     if (val == val) {  // dropped replicates are stored as NaN
@@ -113,10 +113,12 @@ __global__ __launch_bounds__(K9_THREADS) void k_contract_stats(const double *__r
       s_sq += d * d;
       double nul = val - c0;
       if (nul > a0 || nul < -a0) s_ext += 1.0;
+      if (val > a0 || val < -a0) s_raw += 1.0;   // null NOT centred on the observed value (resampling != 'bootstrap')
     }
   }
   double sq = wg_sum(s_sq, red);
   double ext = wg_sum(s_ext, red);
+  double raw = wg_sum(s_raw, red);
   if (threadIdx.x == 0) {
     st[0] = c0;
     st[1] = cnt > 0 ? sqrt(sq / cnt) : NAN;
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(K9_THREADS) void k_contract_stats(const double *__r
     st[3] = ext;
     st[4] = mean1 - c0;
     st[5] = (mn == mx) ? 1.0 : 0.0;
-    st[6] = mn;
-    st[7] = mx;
+    st[6] = raw;
+    st[7] = mx - mn;
   }
 }
 
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
   double c0 = crow[0];
   double mean1 = cnt > 0 ? tot / cnt : NAN;
   double a0 = fabs(c0);
-  double s_sq = 0.0, s_ext = 0.0;
+  double s_sq = 0.0, s_ext = 0.0, s_raw = 0.0;
   for (int c = 1 + threadIdx.x; c < num_boot; c += K9_THREADS) {
     double val = crow[c];
     if (val == val) {
@@ -286,10 +288,12 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
       s_sq += d * d;
       double nul = val - c0;
       if (nul > a0 || nul < -a0) s_ext += 1.0;
+      if (val > a0 || val < -a0) s_raw += 1.0;   // null NOT centred on the observed value (resampling != 'bootstrap')
     }
   }
   double sq = wg_sum(s_sq, red);
   double ext = wg_sum(s_ext, red);
+  double raw = wg_sum(s_raw, red);
   if (threadIdx.x == 0) {
     st[0] = c0;
     st[1] = cnt > 0 ? sqrt(sq / cnt) : NAN;
@@ -297,8 +301,8 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
     st[3] = ext;
     st[4] = mean1 - c0;
     st[5] = (mn == mx) ? 1.0 : 0.0;
-    st[6] = mn;
-    st[7] = mx;
+    st[6] = raw;
+    st[7] = mx - mn;
   }
 }
 
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(K9_THREADS) void k_contrast_stats(const double *__r
   double c0m = ma[0] - mc[0], c0v = va[0] - vc[0];
   double mean_m = n > 0 ? tm / n : NAN, mean_v = n > 0 ? tv / n : NAN;
   double am = fabs(c0m), av = fabs(c0v);
-  double sq_m = 0, sq_v = 0, ex_m = 0, ex_v = 0;
+  double sq_m = 0, sq_v = 0, ex_m = 0, ex_v = 0, rw_m = 0, rw_v = 0;
   for (int c = 1 + threadIdx.x; c < n_cols; c += K9_THREADS) {
     double a = ma[c], b = mc[c], p = va[c], q = vc[c];
     if (isfinite(a) && isfinite(b) && isfinite(p) && isfinite(q)) {
@@ -356,14 +360,17 @@ __global__ __launch_bounds__(K9_THREADS) void k_contrast_stats(const double *__r
       double nm = dm - c0m, nv = dv - c0v;
       if (nm > am || nm < -am) ex_m += 1.0;
       if (nv > av || nv < -av) ex_v += 1.0;
+      if (dm > am || dm < -am) rw_m += 1.0;
+      if (dv > av || dv < -av) rw_v += 1.0;
     }
   }
   double qm = wg_sum(sq_m, red), qv = wg_sum(sq_v, red), em = wg_sum(ex_m, red), ev = wg_sum(ex_v, red);
+  double rm = wg_sum(rw_m, red), rv = wg_sum(rw_v, red);
   if (threadIdx.x == 0) {
     sm_[0] = c0m; sm_[1] = n > 0 ? sqrt(qm / n) : NAN; sm_[2] = n; sm_[3] = em; sm_[4] = mean_m - c0m;
-    sm_[5] = (lo_m == hi_m) ? 1.0 : 0.0; sm_[6] = lo_m; sm_[7] = hi_m;
+    sm_[5] = (lo_m == hi_m) ? 1.0 : 0.0; sm_[6] = rm; sm_[7] = hi_m - lo_m;
     sv_[0] = c0v; sv_[1] = n > 0 ? sqrt(qv / n) : NAN; sv_[2] = n; sv_[3] = ev; sv_[4] = mean_v - c0v;
-    sv_[5] = (lo_v == hi_v) ? 1.0 : 0.0; sv_[6] = lo_v; sv_[7] = hi_v;
+    sv_[5] = (lo_v == hi_v) ? 1.0 : 0.0; sv_[6] = rv; sv_[7] = hi_v - lo_v;
   }
 }
 

@@ -26,13 +26,14 @@ def _gev_tail(tail, at, upper):
     return None
 
 
-def tail_fit_asl(coef_row, extreme_count):
+def tail_fit_asl(coef_row, extreme_count, centred=True):
     """ASL of one test whose two-sided extreme count is <= 10.  ``coef_row``: coefficient per replicate
-    column with column 0 = observed value; NaN marks dropped replicate columns."""
+    column with column 0 = observed value; NaN marks dropped replicate columns.  ``centred``: the null is
+    coef[1:] - coef[0] (resampling == 'bootstrap'), else coef[1:] as it is (hypothesis_test.py:66-70)."""
     row = np.asarray(coef_row, dtype=np.float64)
     row = row[~np.isnan(row)]
     stat = row[0]
-    null = row[1:] - stat
+    null = row[1:] - stat if centred else row[1:]
     null = null[np.isfinite(null)]
     fallback = (extreme_count + 1) / (null.shape[0] + 1)
     a = abs(stat)
@@ -111,14 +112,19 @@ class _main_hidden:
         return False
 
 
-def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1):
+def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1, resampling='bootstrap'):
     """Vector of ASLs for all tests.
 
-    ``stats_arr`` [n_tests][8] = {coef0, se, n_valid, extreme_count, null_mean, all_equal, min, max};
-    ``fetch_rows(idx)`` returns the coefficient rows (host, [len(idx)][B+1]) of the tests that need a tail fit.
+    ``stats_arr`` [n_tests][8] = {coef0, se, n_valid, extreme_count, null_mean, all_equal, extreme_count_raw, range}
+    (include/memento_hip.h); ``fetch_rows(idx)`` returns the coefficient rows (host, [len(idx)][B+1]) of the tests that
+    need a tail fit.  ``resampling``: 'bootstrap' centres the null on the observed value, anything else does not
+    (hypothesis_test.py:66-70) -- the replicates themselves are the same bootstrap either way.
     """
     st = np.asarray(stats_arr)
     coef0, se, n, c, nmean, alleq = st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], st[:, 5]
+    centred = resampling == 'bootstrap'
+    if not centred:
+        c, nmean = st[:, 6], nmean + coef0
     asl = np.full(st.shape[0], np.nan)
     live = np.isfinite(coef0) & (alleq == 0) & (n > 0)
     if approx:
@@ -131,7 +137,7 @@ def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1):
     need = np.flatnonzero(live & (c <= 10))
     if len(need):
         rows = fetch_rows(need)
-        jobs = [(rows[i], float(c[t])) for i, t in enumerate(need)]
+        jobs = [(rows[i], float(c[t]), centred) for i, t in enumerate(need)]
         if num_cpus and num_cpus > 1 and len(jobs) > 1:
             with _main_hidden():        # workers are spawned on submit
                 it = get_pool(num_cpus).map(_tail_job, jobs, chunksize=max(1, len(jobs) // (4 * num_cpus)))

@@ -329,8 +329,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     """
     if 'resampling' not in kwargs:
         raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
-    if kwargs['resampling'] != 'bootstrap':
-        raise NotImplementedError("only resampling='bootstrap' is implemented on the HIP path")
+    resampling = kwargs['resampling']       # 'bootstrap' centres the null on the observed value, anything else does not (:66-70)
     resample_rep = bool(kwargs.get('resample_rep', False))
     if rng not in ('replay', 'fast'):
         raise ValueError("rng must be 'replay' or 'fast'")
@@ -512,7 +511,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 coef[rr_idx] = coef_r[rr_idx]
             no_group = ~good[np.asarray(test_gene, dtype=np.int64)].any(axis=1) if n_tests else np.zeros(0, bool)
             c0, se = stt[:, 0].copy(), stt[:, 1].copy()
-            p = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
+            p = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus, resampling)
             c0[no_group], se[no_group], p[no_group] = np.nan, np.nan, np.nan                              # hypothesis_test.py:203-204
             out[tag + '_coef'], out[tag + '_se'], out[tag + '_asl'] = c0, se, p
         st.last_bootstrap = bs
@@ -537,7 +536,8 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         return adata
 
 
-def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', fill_seed=0, max_rows=None, approx=False):
+def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', fill_seed=0, max_rows=None, approx=False,
+                     resampling='bootstrap'):
     """Perturb-seq style batch test: every group against one shared ``control`` group (a label of
     ``adata.uns['memento']['groups']`` or its index), for all kept genes, in one call.
 
@@ -587,7 +587,7 @@ def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', f
         test_grp = np.tile(np.asarray(others), G)
         st_m, st_v, rows = bs.contrast(test_gene, test_grp, ctrl, good)
         for tag, stt, which in (('mean', st_m, 0), ('var', st_v, 1)):
-            p = _asl.asl_from_stats(stt, approx, lambda idx, w=which: rows(w, idx), num_cpus)
+            p = _asl.asl_from_stats(stt, approx, lambda idx, w=which: rows(w, idx), num_cpus, resampling)
             cols[tag + '_coef'].append(stt[:, 0])
             cols[tag + '_se'].append(stt[:, 1])
             cols[tag + '_asl'].append(p)
@@ -696,8 +696,9 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     hypothesis_test._ht_2d :303-364).  Same replay semantics as ht_1d_moments."""
     if 'resampling' not in kwargs:
         raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
-    if kwargs['resampling'] != 'bootstrap' or kwargs.get('resample_rep', False) or treatment_for_gene is not None:
-        raise NotImplementedError("HIP path: resampling='bootstrap', resample_rep=False, treatment_for_gene=None")
+    if kwargs.get('resample_rep', False) or treatment_for_gene is not None:
+        raise NotImplementedError("HIP path (2D): resample_rep=False, treatment_for_gene=None")
+    resampling = kwargs['resampling']
     approx = bool(kwargs.get('approx', False))
     if not inplace:
         adata = adata.copy()
@@ -763,7 +764,7 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             rows.append(W)
         Wmat = np.concatenate(rows, axis=0) if rows else np.zeros((0, ng))
         coef, stt = bs.contract(np.arange(n_ch), Wmat, good)
-        pvals = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus)
+        pvals = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus, resampling)
         for k in range(n_ch):
             c = int(first[lo + so[k]])
             if not good[k].any():

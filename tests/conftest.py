@@ -34,6 +34,11 @@ def api_meanonly():
 
 
 @pytest.fixture(scope="session")
+def api_perm():
+    return load_golden("api_perm")
+
+
+@pytest.fixture(scope="session")
 def internals_small():
     return load_golden("internals_small")
 

@@ -231,7 +231,41 @@ def regress_asl_case(name, seed):
     print(name, {k: float(out[k]) for k in out if k.startswith("asl_out")})
 
 
+def perm_case(name, num_boot, ht_seed):
+    """resampling='permutation' (47 call sites in the reference's analyses): same bootstrap replicates, but _compute_asl
+    does not centre the null on the observed value (hypothesis_test.py:66-70).  Inputs = those of api_small."""
+    adata = synth_adata(1600, 120, 0.12, 2, 2, 11, dtype=np.float64)          # == api_small
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    m = adata.uns["memento"]
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == 1).astype(float)}, index=gdf.index)
+    out = {"num_boot": np.int64(num_boot), "ht_seed": np.int64(ht_seed), "gene_list": np.array(m["gene_list"])}
+    for tag, approx, off in (("exact", False, 0), ("approx", True, 1)):
+        np.random.seed(ht_seed + off)
+        memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=num_boot, num_cpus=1, verbose=0,
+                              resampling="permutation", approx=approx)
+        for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+            out[f"ht_{tag}_{k}"] = np.asarray(m["1d_ht"][k]).copy()
+    ref = np.load(os.path.join(HERE, "api_small.npz"))
+    names = adata.var.index.values
+    pairs = list(zip(names[ref["pair_idx1"]].tolist(), names[ref["pair_idx2"]].tolist()))
+    memento.compute_2d_moments(adata, pairs)
+    np.random.seed(ht_seed + 2)
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=num_boot, num_cpus=1, verbose=0,
+                          resampling="permutation", approx=False)
+    for k in ["corr_coef", "corr_se", "corr_asl"]:
+        out["ht2_" + k] = np.asarray(m["2d_ht"][k]).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "genes", len(out["gene_list"]), "finite p", np.isfinite(out["ht_exact_mean_asl"]).sum())
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["perm"]:            # only the newest fixture (the others are reproduced bit for bit by a full run)
+        perm_case("api_perm", num_boot=300, ht_seed=21)
+        sys.exit(0)
     ad = api_case("api_small", n_cells=1600, n_genes=120, density=0.12, n_cond=2, n_rep=2, seed=11,
                   num_boot=300, ht_seed=3, approx=False, two_d_pairs=12)
     internals_case("internals_small", ad, picks=[(0, 0), (3, 1), (7, 2), (11, 3), (20, 0)], num_boot=64, seed=100)
@@ -240,3 +274,4 @@ if __name__ == "__main__":
     api_case("api_meanonly", n_cells=1500, n_genes=90, density=0.15, n_cond=2, n_rep=2, seed=31,
              num_boot=150, ht_seed=9, approx=True, estimator_type="mean_only")
     regress_asl_case("regress_asl", seed=5)
+    perm_case("api_perm", num_boot=300, ht_seed=21)

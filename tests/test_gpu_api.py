@@ -88,6 +88,38 @@ def test_ht_1d_strict_replay_matches_reference(fx, request):
     assert len(df) == len(g["gene_list"])
 
 
+@pytest.mark.parametrize("tag,approx,off", [("exact", False, 0), ("approx", True, 1)])
+def test_ht_1d_permutation_resampling_matches_reference(api_small, api_perm, tag, approx, off):
+    """resampling='permutation' (as common as 'bootstrap' in the reference's analyses): same replicates, un-centred null."""
+    g, gp = api_small, api_perm
+    memento, adata = _run_to_moments(g)
+    cov, trt = _design(memento, adata, g)
+    np.random.seed(int(gp["ht_seed"]) + off)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(gp["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="permutation", approx=approx, strict=True)
+    ht = adata.uns["memento"]["1d_ht"]
+    for k in ["mean_coef", "mean_se", "var_coef", "var_se"]:
+        np.testing.assert_allclose(ht[k], gp[f"ht_{tag}_{k}"], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+    for k in ["mean_asl", "var_asl"]:
+        np.testing.assert_allclose(ht[k], gp[f"ht_{tag}_{k}"], rtol=1e-5, atol=1e-12, equal_nan=True, err_msg=k)
+
+
+def test_ht_2d_permutation_resampling_matches_reference(api_small, api_perm):
+    g, gp = api_small, api_perm
+    memento, adata = _run_to_moments(g)
+    names = np.asarray(adata.var.index)
+    pairs = list(zip(names[g["pair_idx1"]].tolist(), names[g["pair_idx2"]].tolist()))
+    memento.compute_2d_moments(adata, pairs)
+    cov, trt = _design(memento, adata, g)
+    np.random.seed(int(gp["ht_seed"]) + 2)
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=int(gp["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="permutation", approx=False)
+    ht = adata.uns["memento"]["2d_ht"]
+    np.testing.assert_allclose(ht["corr_coef"], gp["ht2_corr_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(ht["corr_se"], gp["ht2_corr_se"], rtol=1e-8, equal_nan=True)
+    np.testing.assert_allclose(ht["corr_asl"], gp["ht2_corr_asl"], rtol=1e-5, equal_nan=True)
+
+
 def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     """strict=False: identical multinomial replay, but invalid replicates are refilled on the device with a
     counter-based RNG -> observed coefficients identical, SEs/p-values agree within Monte-Carlo error and

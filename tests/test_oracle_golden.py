@@ -137,3 +137,17 @@ def test_ht_1d_resample_rep(api_small):
                     g["group_q"], resampling="bootstrap", approx=False, resample_rep=True)
     for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], out):
         np.testing.assert_allclose(v, g["htrr_" + k], rtol=1e-7, equal_nan=True, err_msg=k)
+
+
+@pytest.mark.parametrize("tag,approx,off", [("exact", False, 0), ("approx", True, 1)])
+def test_ht_1d_permutation_resampling(api_small, api_perm, tag, approx, off):
+    """resampling='permutation': the null is not centred on the observed value (hypothesis_test.py:66-70)."""
+    g, gp = api_small, api_perm
+    X, gid, ng, q = golden_inputs(g)
+    keep = g["overall_gene_filter"]
+    mom = dict(mean=g["mean"], res_var=g["res_var"], mv_fit=g["mv_regressor"])
+    np.random.seed(int(gp["ht_seed"]) + off)
+    out = orc.ht_1d(X[:, keep], gid, ng, g["approx_sf"], mom, g["covariate"], g["treatment"], int(gp["num_boot"]),
+                    g["group_q"], resampling="permutation", approx=approx)
+    for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], out):
+        np.testing.assert_allclose(v, gp[f"ht_{tag}_{k}"], rtol=1e-7, equal_nan=True, err_msg=k)
