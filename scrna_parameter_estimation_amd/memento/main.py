@@ -268,7 +268,7 @@ def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=Tru
     if gene_list is not None:                                                                  # main.py:258-271
         assert type(gene_list) == list
         names = _var_names(adata)
-        given = np.in1d(names, gene_list)
+        given = np.isin(names, gene_list)
         for g in groups:
             m['1d_moments'][g] = [a[given] for a in m['1d_moments'][g]]
             m['group_cells'][g] = _GroupCellsView(m['group_cells'][g].shape[0], int(given.sum()))

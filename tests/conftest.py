@@ -39,6 +39,11 @@ def api_perm():
 
 
 @pytest.fixture(scope="session")
+def api_opts():
+    return load_golden("api_opts")
+
+
+@pytest.fixture(scope="session")
 def internals_small():
     return load_golden("internals_small")
 

@@ -262,7 +262,69 @@ def perm_case(name, num_boot, ht_seed):
     print(name, "genes", len(out["gene_list"]), "finite p", np.isfinite(out["ht_exact_mean_asl"]).sum())
 
 
+def opts_case(name):
+    """Non-default options the reference's analyses use a lot: setup_memento(filter_mean_thresh, trim_percent, shrinkage,
+    num_bins), compute_1d_moments(filter_genes=False) and compute_1d_moments(gene_list=[...]).  Inputs = those of api_small."""
+    out = {}
+
+    def fresh(**kw):
+        adata = synth_adata(1600, 120, 0.12, 2, 2, 11, dtype=np.float64)          # == api_small
+        memento.setup_memento(adata, q_column="q", **kw)
+        memento.create_groups(adata, label_columns=["cond", "rep"])
+        return adata
+
+    # (a) other setup parameters
+    kw = dict(filter_mean_thresh=0.05, trim_percent=0.2, shrinkage=0.4, num_bins=20)
+    adata = fresh(**kw)
+    m = adata.uns["memento"]
+    groups = list(m["groups"])
+    out["a_size_factor"] = adata.obs["memento_size_factor"].values.copy()
+    out["a_least_variable_genes"] = np.array(m["least_variable_genes"])
+    memento.compute_1d_moments(adata, min_perc_group=0.5)
+    out["a_approx_sf"] = m["all_approx_size_factor"].copy()
+    out["a_gene_list"] = np.array(m["gene_list"])
+    out["a_mean"] = np.stack([m["1d_moments"][g][0] for g in groups])
+    out["a_res_var"] = np.stack([m["1d_moments"][g][2] for g in groups])
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == 1).astype(float)}, index=gdf.index)
+    np.random.seed(41)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=200, num_cpus=1, verbose=0, resampling="bootstrap", approx=True)
+    for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+        out["a_ht_" + k] = np.asarray(m["1d_ht"][k]).copy()
+    # (b) filter_genes=False
+    adata = fresh()
+    m = adata.uns["memento"]
+    memento.compute_1d_moments(adata, min_perc_group=0.7, filter_genes=False)
+    out["b_n_vars"] = np.int64(adata.shape[1])
+    out["b_gene_list"] = np.array(m["gene_list"])
+    out["b_mean"] = np.stack([m["1d_moments"][g][0] for g in groups])
+    out["b_var"] = np.stack([m["1d_moments"][g][1] for g in groups])
+    out["b_res_var"] = np.stack([m["1d_moments"][g][2] for g in groups])
+    out["b_mv_regressor"] = np.asarray(m["mv_regressor"]["all"]).copy()
+    out["b_gene_rv_filter"] = np.stack([m["gene_rv_filter"][g] for g in groups])
+    # (c) gene_list
+    adata = fresh()
+    m = adata.uns["memento"]
+    ref = np.load(os.path.join(HERE, "api_small.npz"))
+    chosen = [str(x) for x in ref["gene_list"][::3]] + ["not_a_gene"]
+    out["c_chosen"] = np.array(chosen)
+    memento.compute_1d_moments(adata, min_perc_group=0.7, gene_list=chosen)
+    out["c_var_names"] = np.array(adata.var.index.tolist())
+    out["c_mean"] = np.stack([m["1d_moments"][g][0] for g in groups])
+    out["c_res_var"] = np.stack([m["1d_moments"][g][2] for g in groups])
+    np.random.seed(43)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=200, num_cpus=1, verbose=0, resampling="bootstrap", approx=False)
+    for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+        out["c_ht_" + k] = np.asarray(m["1d_ht"][k]).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "a genes", len(out["a_gene_list"]), "b vars", int(out["b_n_vars"]), "c genes", len(out["c_var_names"]))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["opts"]:
+        opts_case("api_opts")
+        sys.exit(0)
     if sys.argv[1:] == ["perm"]:            # only the newest fixture (the others are reproduced bit for bit by a full run)
         perm_case("api_perm", num_boot=300, ht_seed=21)
         sys.exit(0)
@@ -275,3 +337,4 @@ if __name__ == "__main__":
              num_boot=150, ht_seed=9, approx=True, estimator_type="mean_only")
     regress_asl_case("regress_asl", seed=5)
     perm_case("api_perm", num_boot=300, ht_seed=21)
+    opts_case("api_opts")
