@@ -50,3 +50,18 @@ def shard_genes(n_genes, rank, world):
     lo = (n_genes * rank) // world
     hi = (n_genes * (rank + 1)) // world
     return lo, hi
+
+
+def shard_pairs(gene_pairs, rank, world):
+    """Block of the gene-pair list owned by ``rank`` (2D path: compute_2d_moments / ht_2d_moments).
+
+    Pairs are independent (reference: memento/main.py:485-501), so every rank runs the unchanged 2D API on its own
+    block and there is no collective; each rank needs the count columns of the genes in its block only
+    (SURVEY.md section 8e).  Pairs are ordered by (first gene, second gene) before cutting, so a rank's block
+    touches few distinct first genes; the inverse permutation puts gathered results back in the caller's order.
+    Returns (pairs of this rank, their positions in ``gene_pairs``)."""
+    order = sorted(range(len(gene_pairs)), key=lambda i: (str(gene_pairs[i][0]), str(gene_pairs[i][1])))
+    lo = (len(order) * rank) // world
+    hi = (len(order) * (rank + 1)) // world
+    mine = order[lo:hi]
+    return [gene_pairs[i] for i in mine], np.asarray(mine, dtype=np.int64)

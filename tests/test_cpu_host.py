@@ -272,3 +272,20 @@ def test_pack_and_pair_tiles_are_a_valid_schedule():
     # fast mode: dense 64-wide tiles
     sd, nd = engine.pack_lanes(K[:1000], 2000, dense=True)
     assert nd == 16 and (np.bincount(sd // 64)[:15] == 64).all()
+
+
+def test_shard_pairs_partitions_the_pair_list():
+    from scrna_parameter_estimation_amd.dist import shard_pairs
+
+    rng = np.random.default_rng(1)
+    genes = [f"g{i}" for i in range(40)]
+    pairs = [(genes[a], genes[b]) for a, b in rng.integers(0, 40, size=(500, 2))]
+    for world in (1, 2, 8):
+        seen = np.zeros(len(pairs), dtype=int)
+        sizes = []
+        for r in range(world):
+            mine, pos = shard_pairs(pairs, r, world)
+            assert [pairs[i] for i in pos] == mine
+            seen[pos] += 1
+            sizes.append(len(mine))
+        assert (seen == 1).all() and max(sizes) - min(sizes) <= 1

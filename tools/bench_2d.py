@@ -6,6 +6,7 @@ import numpy as np, pandas as pd, torch, scipy.sparse as sp
 import bench
 from scrna_parameter_estimation_amd import AnnDataLite, memento
 
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
 cells, genes, nl, nr, B = [int(x) for x in sys.argv[1:6]] if len(sys.argv) > 5 else (100_000, 4000, 60, 60, 500)
 cfg = dict(cells=cells, genes=genes, density=0.08)
 csr = bench.synth_device_csr(cfg, 3, torch)
@@ -20,6 +21,11 @@ names = memento.main._var_names(adata)
 print("genes kept", len(names))
 left, right = names[:nl], names[nl:nl + nr]
 pairs = [(a, b) for a in left for b in right]
+# multi-GPU: one process per GPU (RANK / WORLD_SIZE), every rank tests its own block of pairs -- no collective
+rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+if world > 1:
+    from scrna_parameter_estimation_amd.dist import shard_pairs
+    pairs, _ = shard_pairs(pairs, rank, world)
 gdf = memento.get_groups(adata)
 cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
 trt = pd.DataFrame({"cond": gdf["cond"].astype(float)}, index=gdf.index)
