@@ -103,6 +103,35 @@ def test_asl_from_stats_matches_golden(regress_asl):
     np.testing.assert_allclose(got, want[3:], rtol=1e-9)
 
 
+def test_asl_from_stats_uncentred_null_matches_oracle():
+    """resampling != 'bootstrap': the null is coef[1:] itself (hypothesis_test.py:69-70); counting, normal and tail-fit
+    branches against the oracle's compute_asl (itself pinned by the api_perm fixture from the real reference)."""
+    sys.path.insert(0, ROOT)
+    from oracle import memento_oracle as orc
+    from scrna_parameter_estimation_amd.memento import asl
+
+    rng = np.random.default_rng(4)
+    rows = []
+    for stat, loc in ((0.3, 0.0), (2.9, 0.0), (-3.1, 0.1), (0.0, 1.0), (1.2, -0.5)):   # many / few extreme replicates
+        rows.append(np.concatenate([[stat], rng.normal(loc, 1.0, size=1500)]))
+    rows = np.stack(rows)
+    rows[2, 7] = np.nan                                                                # a dropped replicate column
+    st = []
+    for row in rows:
+        v = row[1:][~np.isnan(row[1:])]
+        null, a = v - row[0], abs(row[0])
+        st.append([row[0], v.std(), len(v), float((null > a).sum() + (null < -a).sum()), null.mean(), 0.0,
+                   float((v > a).sum() + (v < -a).sum()), np.nanmax(row) - np.nanmin(row)])
+    st = np.array(st)
+    for approx in (False, True):
+        got = asl.asl_from_stats(st, approx, lambda idx: rows[idx], num_cpus=1, resampling="permutation")
+        want = [orc.compute_asl(r[~np.isnan(r)], "permutation", approx) for r in rows]
+        np.testing.assert_allclose(got, want, rtol=1e-9)
+        got_b = asl.asl_from_stats(st, approx, lambda idx: rows[idx], num_cpus=1, resampling="bootstrap")
+        want_b = [orc.compute_asl(r[~np.isnan(r)], "bootstrap", approx) for r in rows]
+        np.testing.assert_allclose(got_b, want_b, rtol=1e-9)
+
+
 def test_plan_blocks():
     from scrna_parameter_estimation_amd.engine import plan_blocks
 
