@@ -29,6 +29,11 @@ PACK_WAVES = int(os.environ.get('MM_PACK_WAVES', 2000))
 _PACK_L = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 56, 64)
 _PACK_US = (1.34, 1.91, 2.35, 2.60, 2.86, 3.13, 3.29, 3.51, 3.88, 4.18, 4.40, 4.58, 4.70, 4.80, 5.25, 5.68, 6.08, 6.44, 6.7, 7.0, 7.25, 7.7, 8.1)
 PACK_COST = np.interp(np.arange(1, 65), _PACK_L, _PACK_US)
+# (c) many-chain regime (more tiles than resident wave slots): 2 x 1024 slots; a SIMD retires ~1.46 lone-wave-seconds of tile
+# time per second (older wave 1.0 + younger ~0.46); a tile may take at most PACK_TAIL of the work-bound run time
+PACK_MAX_RESIDENT = 2048
+PACK_RATE = 1024 * 1.46
+PACK_TAIL = float(os.environ.get('MM_PACK_TAIL', 0.5))
 
 
 def _torch():
@@ -275,7 +280,37 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
             lo_b = mid
         else:
             hi_b = mid
-    return _tiles_from_lanes(np.maximum.accumulate(lanes_for(hi_b).astype(np.int64)), n_act)
+    lanes = np.maximum.accumulate(lanes_for(hi_b).astype(np.int64))
+    if (1.0 / lanes).sum() > PACK_MAX_RESIDENT:
+        # MANY chains (2D pair lists, hundreds of groups): even 64-wide tiles do not fit the resident wave slots, tiles run in
+        # several rounds and the dispatcher refills slots as waves retire.  Then the schedule is work-bound, and what has to be
+        # avoided is a long chain riding in a wide wave (a 64-wide step costs 6x a lone chain's): cap every tile at
+        # T = PACK_TAIL x (total work / machine rate) with the measured step costs, T found as a fixed point because
+        # narrower tiles for the long chains add work.
+        c = PACK_COST
+
+        def width(T):
+            return np.clip(np.searchsorted(c, T / Ks, side="right"), 1, 64)
+
+        def gap(T):
+            L = width(T)
+            return T - PACK_TAIL * float((Ks * c[L - 1] / L).sum()) / PACK_RATE
+
+        lo_t, hi_t = float(Ks[0]) * c[0], float(Ks[0]) * c[63]
+        if gap(lo_t) >= 0:
+            T = lo_t                      # the longest chain, alone in its wave, already is the tail
+        elif gap(hi_t) <= 0:
+            T = hi_t                      # so much work that even the longest chains can ride 64-wide
+        else:
+            for _ in range(40):
+                mid = 0.5 * (lo_t + hi_t)
+                if gap(mid) < 0:
+                    lo_t = mid
+                else:
+                    hi_t = mid
+            T = hi_t
+        lanes = np.maximum.accumulate(width(T).astype(np.int64))
+    return _tiles_from_lanes(lanes, n_act)
 
 
 PAIR_SLOTS = int(os.environ.get("MM_PAIR_SLOTS", 1024))      # SIMDs: tiles t and t + PAIR_SLOTS share one
