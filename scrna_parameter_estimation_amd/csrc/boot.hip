@@ -346,6 +346,7 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
   if (n_tiles == 0) return MM_OK;
   MM_ARG(n_tiles < 2147483647LL);
   // 4 tiles per 256-thread workgroup: tiles t and t + 1024 (+-3) then meet on one SIMD, which engine.pair_tiles relies on
+  // (one tile per workgroup was measured too: worse when everything is resident, a wash in the many-tile regime)
   hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock);
