@@ -568,9 +568,11 @@ def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', f
         max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
     chunk = max(1, int(max_rows) // max(1, ng))
     cols = {k: [] for k in ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')}
+    bs = rows = None
     for g0 in range(0, G_all, chunk):
         g1 = min(G_all, g0 + chunk)
         G = g1 - g0
+        del bs, rows            # release the previous chunk's replicate rows first: the caching allocator hands them back
         bs = engine.Bootstrap1D(st.blocks, st.gene_idx[g0:g1], st.maxx, st.sf_bin, st.sf_table, gq, num_boot)
         skip = _pair_skip(true_mean[:, g0:g1], true_rv[:, g0:g1])
         with np.errstate(invalid="ignore", divide="ignore"):
