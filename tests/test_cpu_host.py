@@ -294,6 +294,18 @@ def test_pack_and_pair_tiles_are_a_valid_schedule():
     assert (np.diff(est[:h]) <= 1e-9).all()            # first half: longest first
     assert (np.diff(est[h:2 * h]) >= -1e-9).all()      # second half: ascending, so tile t meets a short partner at t + h
     assert est[:h].min() >= est[h:].max() - 1e-9
+    # many-chain regime (more tiles than resident wave slots): long chains ride in narrow waves, short ones 64 wide
+    Kb = np.sort(np.clip(rng.lognormal(np.log(260), 0.75, 200_000), 2, 3500).astype(int))[::-1]
+    sb, nb = engine.pack_lanes(Kb, engine.PACK_WAVES)
+    assert nb > 2048 and len(np.unique(sb)) == len(Kb)
+    tb = sb // 64
+    lb = np.bincount(tb, minlength=nb)
+    kb = np.zeros(nb)
+    np.maximum.at(kb, tb, Kb)
+    cost = kb * engine.PACK_COST[lb - 1]
+    assert lb[0] < 8 and lb[-1] == 64 or lb[-2] == 64                  # heaviest chain nearly alone, lightest in full waves
+    assert cost.max() <= max(Kb[0] * engine.PACK_COST[0], engine.PACK_TAIL * cost.sum() / engine.PACK_RATE) * 1.001
+    assert len(np.unique(engine.pair_tiles(sb, nb, Kb))) == len(Kb)
     # degenerate inputs
     assert engine.pack_lanes(np.zeros(0), 2000) [1] == 0
     s1, n1 = engine.pack_lanes(np.array([7]), 2000)
