@@ -31,9 +31,10 @@ _PACK_US = (1.34, 1.91, 2.35, 2.60, 2.86, 3.13, 3.29, 3.51, 3.88, 4.18, 4.40, 4.
 PACK_COST = np.interp(np.arange(1, 65), _PACK_L, _PACK_US)
 # (c) many-chain regime (more tiles than resident wave slots): 2 x 1024 slots; a SIMD retires ~1.46 lone-wave-seconds of tile
 # time per second (older wave 1.0 + younger ~0.46); a tile may take at most PACK_TAIL of the work-bound run time
-PACK_MAX_RESIDENT = 2048
+PACK_MAX_RESIDENT = int(os.environ.get('MM_PACK_MAX_RESIDENT', 2048))
 PACK_RATE = 1024 * 1.46
 PACK_TAIL = float(os.environ.get('MM_PACK_TAIL', 0.5))
+PACK_LAST = {}          # diagnostics of the last pack_lanes decision (tools/)
 
 
 def _torch():
@@ -281,35 +282,50 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
         else:
             hi_b = mid
     lanes = np.maximum.accumulate(lanes_for(hi_b).astype(np.int64))
-    if (1.0 / lanes).sum() > PACK_MAX_RESIDENT:
-        # MANY chains (2D pair lists, hundreds of groups): even 64-wide tiles do not fit the resident wave slots, tiles run in
-        # several rounds and the dispatcher refills slots as waves retire.  Then the schedule is work-bound, and what has to be
-        # avoided is a long chain riding in a wide wave (a 64-wide step costs 6x a lone chain's): cap every tile at
-        # T = PACK_TAIL x (total work / machine rate) with the measured step costs, T found as a fixed point because
-        # narrower tiles for the long chains add work.
-        c = PACK_COST
+    c = PACK_COST
+    # MANY chains (2D pair lists, hundreds of groups): 64-wide tiles no longer fit the resident wave slots, or they fit only
+    # because even the longest chains were made 64 wide (a 64-wide step costs 6x a lone chain's, and that tile then runs
+    # long after everything else has finished).  There the schedule should be work-bound instead: tiles run in several
+    # rounds, the dispatcher refills slots as waves retire, every tile is capped at T = PACK_TAIL x (total work / machine
+    # rate) with the measured step costs -- T is a fixed point because narrower tiles for the long chains add work.
 
-        def width(T):
-            return np.clip(np.searchsorted(c, T / Ks, side="right"), 1, 64)
+    def width(T):
+        return np.clip(np.searchsorted(c, T / Ks, side="right"), 1, 64)
 
-        def gap(T):
-            L = width(T)
-            return T - PACK_TAIL * float((Ks * c[L - 1] / L).sum()) / PACK_RATE
+    def work(L):
+        return float((Ks * c[L - 1] / L).sum()) / PACK_RATE
 
-        lo_t, hi_t = float(Ks[0]) * c[0], float(Ks[0]) * c[63]
-        if gap(lo_t) >= 0:
-            T = lo_t                      # the longest chain, alone in its wave, already is the tail
-        elif gap(hi_t) <= 0:
-            T = hi_t                      # so much work that even the longest chains can ride 64-wide
-        else:
-            for _ in range(40):
-                mid = 0.5 * (lo_t + hi_t)
-                if gap(mid) < 0:
-                    lo_t = mid
-                else:
-                    hi_t = mid
-            T = hi_t
-        lanes = np.maximum.accumulate(width(T).astype(np.int64))
+    def gap(T):
+        return T - PACK_TAIL * work(width(T))
+
+    lo_t, hi_t = float(Ks[0]) * c[0], float(Ks[0]) * c[63]
+    if gap(lo_t) >= 0:
+        T = lo_t                      # the longest chain, alone in its wave, already is the tail
+    elif gap(hi_t) <= 0:
+        T = hi_t                      # so much work that even the longest chains can ride 64-wide
+    else:
+        for _ in range(40):
+            mid = 0.5 * (lo_t + hi_t)
+            if gap(mid) < 0:
+                lo_t = mid
+            else:
+                hi_t = mid
+        T = hi_t
+    lanes_w = np.maximum.accumulate(width(T).astype(np.int64))
+    # choose by predicted run time (in units of lone-wave step time): resident tiles finish when their longest tile does
+    # (measured / predicted: C3 6.21 / 6.25 s; 2D kernel 1.33-1.38x on three sizes); the work-bound schedule takes about 1.35x
+    # the larger of its ideal work time and its tile cap (C3 1.33x; 2D 1.4x on four sizes, after the same kernel factor)
+    longest_resident = float((Ks * c[lanes - 1]).max())
+    n_res = float((1.0 / lanes).sum())
+    use_work_bound = n_res > PACK_MAX_RESIDENT or 1.35 * max(work(lanes_w), T) < longest_resident
+    force = os.environ.get("MM_PACK_FORCE", "")           # tuning hook: "res" / "cap"
+    if force:
+        use_work_bound = force == "cap" or n_res > PACK_MAX_RESIDENT
+    PACK_LAST.update(chains=n_act, tiles_resident=n_res, longest_resident=longest_resident, work_resident=work(lanes),
+                     T_work_bound=T, work_work_bound=work(lanes_w), tiles_work_bound=float((1.0 / lanes_w).sum()),
+                     chosen="work-bound" if use_work_bound else "resident")
+    if use_work_bound:
+        lanes = lanes_w
     return _tiles_from_lanes(lanes, n_act)
 
 

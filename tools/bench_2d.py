@@ -38,3 +38,5 @@ torch.cuda.synchronize(); t2 = time.time()
 ht = adata.uns["memento"]["2d_ht"]
 bs = adata.uns["memento"]["_hip"].last_bootstrap2d
 print(f"pairs={len(pairs)} compute_2d={t1-t0:.3f}s ht_2d={t2-t1:.3f}s -> {len(pairs)/(t2-t0):.1f} pair-tests/s; K mean {bs.K.mean():.0f} max {bs.K.max()}; finite p {np.isfinite(ht['corr_asl']).mean():.3f}")
+from scrna_parameter_estimation_amd import engine
+print("packing:", {k: (round(v, 1) if isinstance(v, float) else v) for k, v in engine.PACK_LAST.items()})
