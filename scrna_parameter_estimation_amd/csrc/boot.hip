@@ -281,19 +281,24 @@ __global__ __launch_bounds__(256) void k_boot2d_replay(const double *__restrict_
   double *oc = out_corr + row * ld + 1;
   npyrng::Pcg64 g{st0, st1, st2, st3};
   const bool run = K >= 1;
+  // operands of the NEXT bin step are loaded while the current one computes (as in k_boot1d_replay): the longest pair runs
+  // alone in its wave and is the critical path of the launch, so an exposed L2 round trip per step is paid in full there
   const int64_t obase = row0 * 64 + lane;
+  double c_pk = pk_[obase], c_lq = lq_[obase], c_x1 = v1_[obase], c_x2 = v2_[obase], c_a = a[obase], c_b = b[obase];
   for (int r = 0; r < num_boot; r++) {
     double A1 = 0.0, A2 = 0.0, MX = 0.0, Q1 = 0.0, Q2 = 0.0;
     int32_t dn = n;
     bool live = true;
     for (int k = 0; k < kmax; k++) {
+      int kn = k + 1 < kmax ? k + 1 : 0;
+      int64_t on = obase + (int64_t)kn * 64;
+      double n_pk = pk_[on], n_lq = lq_[on], n_x1 = v1_[on], n_x2 = v2_[on], n_a = a[on], n_b = b[on];
       if (run && k < K) {
-        int64_t o = obase + (int64_t)k * 64;
         int32_t w;
         if (k < K - 1) {
           w = 0;
           if (live) {
-            w = npyrng::binomial_pre<int32_t>(g, pk_[o], lq_[o], dn);
+            w = npyrng::binomial_pre<int32_t>(g, c_pk, c_lq, dn);
             dn -= w;
             if (dn <= 0) live = false;
           }
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void k_boot2d_replay(const double *__restrict_
           w = dn > 0 ? dn : 0;
         }
         if (w != 0) {
-          double wd = (double)w, x1 = v1_[o], x2 = v2_[o], aa = a[o], bb = b[o];
+          double wd = (double)w, x1 = c_x1, x2 = c_x2, aa = c_a, bb = c_b;
           A1 += (x1 * wd) * aa;
           A2 += (x2 * wd) * aa;
           MX += ((x1 * x2) * wd) * bb;
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(256) void k_boot2d_replay(const double *__restrict_
           Q2 += ((x2 * x2) * wd) * bb - ((omq * x2) * wd) * bb;
         }
       }
+      c_pk = n_pk; c_lq = n_lq; c_x1 = n_x1; c_x2 = n_x2; c_a = n_a; c_b = n_b;
     }
     if (run) {
       double m1 = A1 / nobs, m2 = A2 / nobs;
