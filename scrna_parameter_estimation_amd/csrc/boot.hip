@@ -15,12 +15,15 @@
 #include "npy_rng.h"
 
 #ifndef BOOT_MIN_WAVES
-#define BOOT_MIN_WAVES 1
+#define BOOT_MIN_WAVES 2
 #endif
 #ifndef BOOT_SETPRIO
 #define BOOT_SETPRIO 2
 #endif
-__global__ __launch_bounds__(256, BOOT_MIN_WAVES) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
+// MINW = waves per SIMD the register budget is set for: 2 when every tile is resident (<= 2048 tiles, the pairing order below
+// assumes two per SIMD), 3 in the many-tile regime where a third resident wave adds a little issue throughput.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v, const double *__restrict__ a,
                                                        const double *__restrict__ b,
                                                        const int64_t *__restrict__ tile_ptr, int64_t n_tiles,
@@ -257,7 +260,8 @@ __global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ 
 // covariance and the two variances (bootstrap.py:141-155, estimator.py:214-218, :171-174) are folded
 // into the correlation exactly as estimator._corr_from_cov does (:281-292: 5.0 sentinel where a variance
 // is <= 0, then clip to [-1, 1]).  Writes corr_b to out[row*ld + 1 + b].
-__global__ __launch_bounds__(256) void k_boot2d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v1_, const double *__restrict__ v2_,
                                                        const double *__restrict__ a, const double *__restrict__ b,
                                                        const int64_t *__restrict__ tile_ptr, int64_t n_tiles,
@@ -353,7 +357,8 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
   MM_ARG(n_tiles < 2147483647LL);
   // 4 tiles per 256-thread workgroup: tiles t and t + 1024 (+-3) then meet on one SIMD, which engine.pair_tiles relies on
   // (one tile per workgroup was measured too: worse when everything is resident, a wash in the many-tile regime)
-  hipLaunchKernelGGL(k_boot1d_replay, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
+  auto kern = n_tiles > 2048 ? k_boot1d_replay<3> : k_boot1d_replay<BOOT_MIN_WAVES>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock);
   MM_LAUNCH_CHECK();
@@ -379,7 +384,8 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
   MM_ARG(d_pk && d_lq && d_v1 && d_v2 && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   MM_ARG(d_out_corr && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
-  hipLaunchKernelGGL(k_boot2d_replay, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
+  auto kern = n_tiles > 2048 ? k_boot2d_replay<3> : k_boot2d_replay<BOOT_MIN_WAVES>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, ld, d_out_corr);
   MM_LAUNCH_CHECK();
