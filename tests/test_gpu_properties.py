@@ -99,6 +99,32 @@ def test_histograms_and_multinomial_invariants(big):
     assert np.isfinite(rm[bs.active]).all() and (rm[bs.active] >= 0).all()
 
 
+def test_replay_is_independent_of_the_packing(big, monkeypatch):
+    """The same chains packed as > 2048 single-chain tiles (many-tile regime: the 3-waves-per-SIMD kernel variant, tiles in
+    several rounds) and as the default wide tiles give bit-identical replicate moments."""
+    engine, torch, csr, gid, blocks, sf = big
+    S, sumx, maxx = blocks.moments(1.0 / sf)
+    rng = np.random.default_rng(21)
+    ng = blocks.n_groups
+    genes = np.sort(rng.choice(np.flatnonzero(sumx.sum(axis=0) > 2000), size=-(-2300 // ng), replace=False))
+    n_bins = 31
+    sf_bin = rng.integers(0, n_bins, size=csr.shape[0]).astype(np.uint8)
+    sf_table = np.linspace(0.4, 2.5, n_bins)
+    B = 40
+    out = []
+    for waves in (engine.PACK_WAVES, 10 ** 7):
+        monkeypatch.setattr(engine, "PACK_MAX_RESIDENT", 2048 if waves == engine.PACK_WAVES else 10 ** 9)   # allow 1-chain tiles
+        bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(ng, 0.07), B)
+        r = np.random.default_rng(4).random((2, bs.n_pairs))
+        zeros = np.zeros(bs.n_pairs)
+        bs.alloc_outputs(zeros, zeros)
+        bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True, target_waves=waves)
+        out.append((bs.n_tiles, engine.host(bs.raw_mean), engine.host(bs.raw_var)))
+    assert out[0][0] <= 2048 < out[1][0]
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
 def test_replay_weights_bit_exact_at_scale(big):
     """BTPE-heavy stress of the samplers on the device: >1e6 draws on 12k-cell (C2) / 48k-cell (C3) groups must equal
     numpy's Generator(PCG64(5)).multinomial draw for draw."""
