@@ -448,7 +448,7 @@ class Bootstrap1D:
         self.ym[:, 0] = dev(np.asarray(true_mean_log, dtype=np.float64))
         self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
 
-    def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0, target_waves=PACK_WAVES,
+    def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0, target_waves=None,
             fast=False, mean_only=False):
         """Order bins, replay the bootstrap and fill/log for every pair >= ``first_pair`` that is not skipped.
 
@@ -464,7 +464,7 @@ class Bootstrap1D:
         order = act[np.argsort(-self.K[act], kind="stable")]
         n_act = len(order)
         # replay: cost-model lane packing (one lane = one sequential chain); fast: dense 64-wide tiles (one WAVE per pair)
-        slot_of, n_tiles = pack_lanes(self.K[order], target_waves, dense=fast)
+        slot_of, n_tiles = pack_lanes(self.K[order], PACK_WAVES if target_waves is None else target_waves, dense=fast)
         if not fast:
             slot_of = pair_tiles(slot_of, n_tiles, self.K[order])
         self.n_tiles = n_tiles
@@ -692,7 +692,7 @@ class Bootstrap2D:
         bi, xi, xj = np.nonzero(tab)
         return bi, xi, xj, tab[bi, xi, xj]
 
-    def run(self, skip, r1a, r1b, r0, true_corr, pcg_seed=5, target_waves=PACK_WAVES):
+    def run(self, skip, r1a, r1b, r0, true_corr, pcg_seed=5, target_waves=None):
         """All arrays are indexed by q = sorted_pair*n_groups + group (see ``self.order``).  Leaves the
         replicate correlations in self.yc [n_q][B+1] (column 0 = true correlation)."""
         torch = _torch()
@@ -703,8 +703,9 @@ class Bootstrap2D:
         if len(act) and (self.K[act] > ORDER_BIG_CAP_2D).any():
             raise NotImplementedError(f"a (pair, group) has more than {ORDER_BIG_CAP_2D} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
-        slot_of, n_tiles = pack_lanes(self.K[order], target_waves)
+        slot_of, n_tiles = pack_lanes(self.K[order], PACK_WAVES if target_waves is None else target_waves)
         slot_of = pair_tiles(slot_of, n_tiles, self.K[order])
+        self.n_tiles = n_tiles
         pair_slot = np.full(self.n_q, -1, dtype=np.int64)
         pair_slot[order] = slot_of
         slot_pair = np.full(n_tiles * 64, -1, dtype=np.int64)

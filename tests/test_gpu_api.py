@@ -177,6 +177,32 @@ def test_setup_and_moments_options_match_reference(api_small, api_opts):
         np.testing.assert_allclose(m["1d_ht"][k], go["c_ht_" + k], rtol=1e-5, atol=1e-12, equal_nan=True, err_msg=k)
 
 
+def test_ht_2d_is_independent_of_the_packing(api_small, monkeypatch):
+    """All 1,891 gene pairs of the fixture, packed as wide resident tiles and as > 2048 single-chain tiles (many-tile regime,
+    3-waves-per-SIMD variant of the 2D kernel): identical coefficients, standard errors and p-values."""
+    from scrna_parameter_estimation_amd import engine
+
+    g = api_small
+    memento, adata = _run_to_moments(g)
+    names = list(adata.var.index)
+    pairs = [(a, b) for i, a in enumerate(names) for b in names[i + 1:]]
+    memento.compute_2d_moments(adata, pairs)
+    cov, trt = _design(memento, adata, g)
+    res = []
+    for waves, resident in ((engine.PACK_WAVES, 2048), (10 ** 7, 10 ** 9)):
+        monkeypatch.setattr(engine, "PACK_WAVES", waves)
+        monkeypatch.setattr(engine, "PACK_MAX_RESIDENT", resident)
+        np.random.seed(5)
+        memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=120, num_cpus=1, verbose=0, resampling="bootstrap",
+                              approx=True)
+        ht = adata.uns["memento"]["2d_ht"]
+        res.append((adata.uns["memento"]["_hip"].last_bootstrap2d.n_tiles, ht["corr_coef"].copy(), ht["corr_se"].copy(), ht["corr_asl"].copy()))
+    assert res[0][0] <= 2048 < res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        np.testing.assert_array_equal(a, b)
+    assert np.isfinite(res[0][3]).mean() > 0.9
+
+
 def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     """strict=False: identical multinomial replay, but invalid replicates are refilled on the device with a
     counter-based RNG -> observed coefficients identical, SEs/p-values agree within Monte-Carlo error and
