@@ -52,6 +52,11 @@ int mm_timer_end(void *timer, void *stream);
 int mm_timer_elapsed_ms(void *timer, float *ms); /* synchronises on the end event */
 int mm_timer_destroy(void *timer);
 
+/* Measurement aid (no reference counterpart): streaming read of n_bytes (multiple of 64 KiB) with the access pattern of
+ * mm_moments1d_sell (64 KiB work items, dwordx4 per lane, 8 rows in flight).  mode 0: loads only -- the read bandwidth this
+ * device reaches for that pattern; 1: + the per-entry 8-byte LDS gather; 2: + the fp64 arithmetic.  tools/hbm_read_peak.py */
+int mm_debug_read_probe(const void *d_src, int64_t n_bytes, int32_t n_workgroups, int32_t mode, uint32_t *d_sink, void *stream);
+
 /* ---- K3: row sums of the CSR, optionally restricted to a gene mask ---------------------------
  * replaces X.sum(axis=1) / X.multiply(mask).sum(axis=1)   memento/estimator.py:65, :73 */
 int mm_csr_rowsum(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows,

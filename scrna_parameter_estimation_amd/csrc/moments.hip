@@ -38,7 +38,10 @@ __device__ __forceinline__ void k1_acc(uint32_t e, const double *__restrict__ w_
   mx = max(mx, x);
 }
 
-__global__ __launch_bounds__(K1_THREADS) void k_moments1d_sell(const u32x4 *__restrict__ ent, const int64_t *__restrict__ blk_base,
+#ifndef K1_MIN_WAVES
+#define K1_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(K1_THREADS, K1_MIN_WAVES) void k_moments1d_sell(const u32x4 *__restrict__ ent, const int64_t *__restrict__ blk_base,
                                                                const int32_t *__restrict__ slice_w, const int32_t *__restrict__ slice_ptr,
                                                                const int32_t *__restrict__ item_ptr, const int64_t *__restrict__ blk_item_base,
                                                                const int32_t *__restrict__ blk_cell0, const double *__restrict__ inv_sf,
@@ -127,12 +130,25 @@ __global__ __launch_bounds__(K1_THREADS) void k_moments1d_sell(const u32x4 *__re
       }
     }
 #endif
-    for (; r < nr; r++) {
-      u32x4 e = __builtin_nontemporal_load(p + (int64_t)r * 64);
-      k1_acc(e.x, w_lds, a1, a2, a3, sx, mx);
-      k1_acc(e.y, w_lds, a1, a2, a3, sx, mx);
-      k1_acc(e.z, w_lds, a1, a2, a3, sx, mx);
-      k1_acc(e.w, w_lds, a1, a2, a3, sx, mx);
+    if (r < nr) {
+      // the last (nr mod UNROLL) rows in ONE batch as well: the row count is wave-uniform, so the guards are scalar branches and
+      // all loads are in flight together (one row at a time would pay the full memory latency up to UNROLL-1 times per item);
+      // a zero word is padding and adds nothing
+      u32x4 e[K1_UNROLL];
+#pragma unroll
+      for (int u = 0; u < K1_UNROLL; u++) {
+        e[u] = u32x4{0u, 0u, 0u, 0u};
+        if (r + u < nr) e[u] = __builtin_nontemporal_load(p + (int64_t)(r + u) * 64);
+      }
+#pragma unroll
+      for (int u = 0; u < K1_UNROLL; u++) {
+        if (r + u < nr) {
+          k1_acc(e[u].x, w_lds, a1, a2, a3, sx, mx);
+          k1_acc(e[u].y, w_lds, a1, a2, a3, sx, mx);
+          k1_acc(e[u].z, w_lds, a1, a2, a3, sx, mx);
+          k1_acc(e[u].w, w_lds, a1, a2, a3, sx, mx);
+        }
+      }
     }
     int64_t o = (ibase + item) * 64 + lane;
     S1[o] = a1;

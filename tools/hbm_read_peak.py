@@ -20,3 +20,22 @@ ms = timeit(lambda: y.copy_(x))
 print(f"copy: {ms:.3f} ms -> {2*x.numel()*4/ms/1e6:.0f} GB/s read+write")
 ms = timeit(lambda: y.fill_(0.0))
 print(f"fill: {ms:.3f} ms -> {x.numel()*4/ms/1e6:.0f} GB/s write")
+
+# the K1 access pattern without its arithmetic (mm_debug_read_probe), HIP-event timed on the current stream
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scrna_parameter_estimation_amd import _lib, engine
+sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+nbytes = (x.numel() * 4 // 65536) * 65536
+timer = ctypes.c_void_p(); _lib.call("mm_timer_create", ctypes.byref(timer)); st = engine._stream()
+xr = torch.randint(0, 2 ** 31 - 1, (x.numel(),), dtype=torch.int32, device="cuda")      # random cell indices / counts for modes 1, 2
+for mode, what in ((0, "loads only"), (1, "+ LDS gather"), (2, "+ LDS gather + fp64 math")):
+    for wgs in (256, 1024, 2048):
+        for _ in range(3):
+            _lib.call("mm_debug_read_probe", engine.P(xr), nbytes, wgs, mode, engine.P(sink), st)
+        _lib.call("mm_timer_begin", timer, st)
+        for _ in range(20):
+            _lib.call("mm_debug_read_probe", engine.P(xr), nbytes, wgs, mode, engine.P(sink), st)
+        _lib.call("mm_timer_end", timer, st)
+        t = ctypes.c_float(); _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(t))
+        print(f"read probe (K1 pattern, {what}), {wgs} workgroups x 1024 threads: {t.value/20:.3f} ms -> {nbytes/(t.value/20)/1e6:.0f} GB/s")
