@@ -54,7 +54,8 @@ int mm_timer_destroy(void *timer);
 
 /* Measurement aid (no reference counterpart): streaming read of n_bytes (multiple of 64 KiB) with the access pattern of
  * mm_moments1d_sell (64 KiB work items, dwordx4 per lane, 8 rows in flight).  mode 0: loads only -- the read bandwidth this
- * device reaches for that pattern; 1: + the per-entry 8-byte LDS gather; 2: + the fp64 arithmetic.  tools/hbm_read_peak.py */
+ * device reaches for that pattern; 1: + the per-entry 8-byte LDS gather; 2: + the fp64 arithmetic; 3: + five result stores per
+ * (chunk, lane) (d_sink must then hold n_bytes / 65536 * 64 * 32 bytes).  tools/hbm_read_peak.py */
 int mm_debug_read_probe(const void *d_src, int64_t n_bytes, int32_t n_workgroups, int32_t mode, uint32_t *d_sink, void *stream);
 
 /* ---- K3: row sums of the CSR, optionally restricted to a gene mask ---------------------------
@@ -90,15 +91,14 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
  * replaces estimator._hyper_1d_relative sparse branch  memento/estimator.py:177-180
  *          and group_cells.mean(axis=0) / .max(axis=0)   memento/main.py:201, :206
  * d_inv_sf[n_sel]: 1/size_factor per selected cell in block order.
- * slab (each [sum(blk_items)][64]): S1 = sum x/sf, S2 = sum x^2/sf^2, S3 = sum x/sf^2 (fp64),
- * SX = sum x (uint32, exact), MX = max x (uint32).  d_blk_item_base = exclusive scan of blk_items. */
+ * d_slab [sum(blk_items)][64] records of 32 bytes: {S1 = sum x/sf, S2 = sum x^2/sf^2, S3 = sum x/sf^2 (fp64),
+ * SX = sum x (uint32, exact), MX = max x (uint32)} -- one contiguous 2 KiB run per work item.
+ * d_blk_item_base = exclusive scan of blk_items. */
 int mm_moments1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const int32_t *d_slice_w, const int32_t *d_slice_ptr,
                       const int32_t *d_item_ptr, const int64_t *d_blk_item_base, const int32_t *d_blk_cell0,
-                      const double *d_inv_sf, int32_t n_blocks, int32_t n_genes, double *d_S1, double *d_S2, double *d_S3,
-                      uint32_t *d_SX, uint32_t *d_MX, void *stream);
+                      const double *d_inv_sf, int32_t n_blocks, int32_t n_genes, void *d_slab, void *stream);
 /* deterministic reduction of the slab over items and over the blocks of each group -> [n_groups][G] */
-int mm_moments1d_reduce(const double *d_S1, const double *d_S2, const double *d_S3, const uint32_t *d_SX, const uint32_t *d_MX,
-                        const int32_t *d_rank, const int32_t *d_item_ptr, const int64_t *d_blk_item_base,
+int mm_moments1d_reduce(const void *d_slab, const int32_t *d_rank, const int32_t *d_item_ptr, const int64_t *d_blk_item_base,
                         const int32_t *d_grp_blk0 /* [n_groups+1] first block of each group */, int32_t n_groups,
                         int32_t n_genes, double *d_out_S /* [3][n_groups][G] */, uint64_t *d_out_sumx /* [n_groups][G] */,
                         uint32_t *d_out_maxx /* [n_groups][G] */, void *stream);

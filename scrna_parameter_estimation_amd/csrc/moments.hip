@@ -45,9 +45,7 @@ __global__ __launch_bounds__(K1_THREADS, K1_MIN_WAVES) void k_moments1d_sell(con
                                                                const int32_t *__restrict__ slice_w, const int32_t *__restrict__ slice_ptr,
                                                                const int32_t *__restrict__ item_ptr, const int64_t *__restrict__ blk_item_base,
                                                                const int32_t *__restrict__ blk_cell0, const double *__restrict__ inv_sf,
-                                                               int32_t n_slices, int32_t split, double *__restrict__ S1,
-                                                               double *__restrict__ S2, double *__restrict__ S3,
-                                                               uint32_t *__restrict__ SX, uint32_t *__restrict__ MX) {
+                                                               int32_t n_slices, int32_t split, u32x4 *__restrict__ slab) {
   __shared__ double w_lds[MM_BLOCK_CELLS];
   __shared__ int32_t ip[K1_MAX_SLICES + 1], sp[K1_MAX_SLICES + 1], sw[K1_MAX_SLICES];
   int b = blockIdx.x / split, part = blockIdx.x % split;
@@ -150,19 +148,21 @@ __global__ __launch_bounds__(K1_THREADS, K1_MIN_WAVES) void k_moments1d_sell(con
         }
       }
     }
-    int64_t o = (ibase + item) * 64 + lane;
-    S1[o] = a1;
-    S2[o] = a2;
-    S3[o] = a3;
-    SX[o] = sx;
-    MX[o] = mx;
+    // one 32-byte record per (item, lane): {S1, S2 | S3, sum x, max x}; a wave writes ONE contiguous 2 KiB run (two dwordx4
+    // stores per lane).  Five separate result arrays cost 10 % of the kernel for 3 % of its bytes (tools/hbm_read_peak.py, mode 3)
+    u32x4 *rec = slab + ((ibase + item) * 64 + lane) * 2;
+    u32x4 r0v, r1v;
+    r0v.x = (uint32_t)__double2loint(a1); r0v.y = (uint32_t)__double2hiint(a1);
+    r0v.z = (uint32_t)__double2loint(a2); r0v.w = (uint32_t)__double2hiint(a2);
+    r1v.x = (uint32_t)__double2loint(a3); r1v.y = (uint32_t)__double2hiint(a3);
+    r1v.z = sx; r1v.w = mx;
+    rec[0] = r0v;
+    rec[1] = r1v;
   }
 }
 
 // Deterministic reduction over the items of a gene's slice and over the blocks of a group.
-__global__ __launch_bounds__(256) void k_moments1d_reduce(const double *__restrict__ S1, const double *__restrict__ S2,
-                                                          const double *__restrict__ S3, const uint32_t *__restrict__ SX,
-                                                          const uint32_t *__restrict__ MX, const int32_t *__restrict__ rank,
+__global__ __launch_bounds__(256) void k_moments1d_reduce(const u32x4 *__restrict__ slab, const int32_t *__restrict__ rank,
                                                           const int32_t *__restrict__ item_ptr, const int64_t *__restrict__ blk_item_base,
                                                           const int32_t *__restrict__ grp_blk0, int32_t n_groups, int32_t n_genes,
                                                           int32_t n_slices, double *__restrict__ out_S, uint64_t *__restrict__ out_sumx,
@@ -179,12 +179,13 @@ __global__ __launch_bounds__(256) void k_moments1d_reduce(const double *__restri
     const int32_t *ip = item_ptr + (int64_t)b * (n_slices + 1);
     int64_t ib = blk_item_base[b];
     for (int it = ip[t]; it < ip[t + 1]; it++) {
-      int64_t o = (ib + it) * 64 + ln;
-      a1 += S1[o];
-      a2 += S2[o];
-      a3 += S3[o];
-      sx += SX[o];
-      mx = max(mx, MX[o]);
+      const u32x4 *rec = slab + ((ib + it) * 64 + ln) * 2;
+      u32x4 lo = rec[0], hi = rec[1];
+      a1 += __hiloint2double((int)lo.y, (int)lo.x);
+      a2 += __hiloint2double((int)lo.w, (int)lo.z);
+      a3 += __hiloint2double((int)hi.y, (int)hi.x);
+      sx += hi.z;
+      mx = max(mx, hi.w);
     }
   }
   int64_t o = (int64_t)grp * n_genes + g;
@@ -200,10 +201,9 @@ extern "C" {
 
 int mm_moments1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const int32_t *d_slice_w, const int32_t *d_slice_ptr,
                       const int32_t *d_item_ptr, const int64_t *d_blk_item_base, const int32_t *d_blk_cell0,
-                      const double *d_inv_sf, int32_t n_blocks, int32_t n_genes, double *d_S1, double *d_S2, double *d_S3,
-                      uint32_t *d_SX, uint32_t *d_MX, void *stream) {
+                      const double *d_inv_sf, int32_t n_blocks, int32_t n_genes, void *d_slab, void *stream) {
   MM_ARG(d_ent && d_blk_base && d_slice_w && d_slice_ptr && d_item_ptr && d_blk_item_base && d_blk_cell0 && d_inv_sf);
-  MM_ARG(d_S1 && d_S2 && d_S3 && d_SX && d_MX && n_blocks >= 0 && n_genes > 0 && n_genes <= 64 * K1_MAX_SLICES);
+  MM_ARG(d_slab && n_blocks >= 0 && n_genes > 0 && n_genes <= 64 * K1_MAX_SLICES);
   if (n_blocks == 0) return MM_OK;
   int32_t n_slices = (n_genes + 63) / 64;
   // enough workgroups to fill 256 CUs x 2 resident (64 KiB LDS each)
@@ -212,20 +212,19 @@ int mm_moments1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const in
   if (split > 64) split = 64;
   hipLaunchKernelGGL(k_moments1d_sell, dim3((unsigned)(n_blocks * split)), dim3(K1_THREADS), 0, (hipStream_t)stream,
                      (const u32x4 *)d_ent, d_blk_base, d_slice_w, d_slice_ptr, d_item_ptr, d_blk_item_base, d_blk_cell0, d_inv_sf,
-                     n_slices, split, d_S1, d_S2, d_S3, d_SX, d_MX);
+                     n_slices, split, (u32x4 *)d_slab);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
-int mm_moments1d_reduce(const double *d_S1, const double *d_S2, const double *d_S3, const uint32_t *d_SX, const uint32_t *d_MX,
-                        const int32_t *d_rank, const int32_t *d_item_ptr, const int64_t *d_blk_item_base,
+int mm_moments1d_reduce(const void *d_slab, const int32_t *d_rank, const int32_t *d_item_ptr, const int64_t *d_blk_item_base,
                         const int32_t *d_grp_blk0, int32_t n_groups, int32_t n_genes, double *d_out_S, uint64_t *d_out_sumx,
                         uint32_t *d_out_maxx, void *stream) {
-  MM_ARG(d_S1 && d_S2 && d_S3 && d_SX && d_MX && d_rank && d_item_ptr && d_blk_item_base && d_grp_blk0);
+  MM_ARG(d_slab && d_rank && d_item_ptr && d_blk_item_base && d_grp_blk0);
   MM_ARG(d_out_S && d_out_sumx && d_out_maxx && n_groups > 0 && n_genes > 0);
   int32_t n_slices = (n_genes + 63) / 64;
-  hipLaunchKernelGGL(k_moments1d_reduce, dim3((n_genes + 255) / 256, n_groups), dim3(256), 0, (hipStream_t)stream, d_S1, d_S2, d_S3,
-                     d_SX, d_MX, d_rank, d_item_ptr, d_blk_item_base, d_grp_blk0, n_groups, n_genes, n_slices, d_out_S,
+  hipLaunchKernelGGL(k_moments1d_reduce, dim3((n_genes + 255) / 256, n_groups), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)d_slab,
+                     d_rank, d_item_ptr, d_blk_item_base, d_grp_blk0, n_groups, n_genes, n_slices, d_out_S,
                      d_out_sumx, d_out_maxx);
   MM_LAUNCH_CHECK();
   return MM_OK;

@@ -10,7 +10,8 @@ struct MmTimer {
 // Streaming-read probe: every wave reads 64 KiB chunks (one dwordx4 per lane per KiB row, 8 rows in flight -- the access
 // pattern of k_moments1d_sell) and folds them into one word.  MODE 0: loads only -> the read bandwidth this device reaches for
 // that pattern, i.e. the practical ceiling of the K1 kernel.  MODE 1: + K1's per-entry LDS gather (8-byte read at the entry's
-// cell index).  MODE 2: + K1's fp64 arithmetic.  (tools/hbm_read_peak.py)
+// cell index).  MODE 2: + K1's fp64 arithmetic.  MODE 3: + K1's five per-(chunk, lane) result stores (sink must then hold
+// 32 bytes per lane per chunk).  (tools/hbm_read_peak.py)
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_read_probe(const u32x4 *__restrict__ src, int64_t n_chunks, uint32_t *__restrict__ sink) {
   __shared__ double w_lds[MODE ? 8192 : 1];
@@ -25,6 +26,10 @@ __global__ __launch_bounds__(1024) void k_read_probe(const u32x4 *__restrict__ s
   double a1 = 0.0, a2 = 0.0, a3 = 0.0;
   for (int64_t c = wave; c < n_chunks; c += n_waves) {
     const u32x4 *p = src + c * 4096 + lane;
+    if (MODE == 3) {
+      a1 = a2 = a3 = 0.0;
+      acc = 0;
+    }
     for (int r = 0; r < 64; r += 8) {
       u32x4 e[8];
 #pragma unroll
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(1024) void k_read_probe(const u32x4 *__restrict__ s
             double w = w_lds[q[j] & 8191];
             if (MODE == 1) {
               a1 += w;
-            } else {
+            } else {  // MODE 2, 3
               double xd = (double)(q[j] >> 13), xw = xd * w, xw2 = xw * w;
               a1 += xw;
               a3 += xw2;
@@ -51,15 +56,25 @@ __global__ __launch_bounds__(1024) void k_read_probe(const u32x4 *__restrict__ s
         }
       }
     }
+    if (MODE == 3) {  // K1's five result streams, 32 bytes per (chunk, lane)
+      double *S1 = (double *)sink, *S2 = S1 + n_chunks * 64, *S3 = S2 + n_chunks * 64;
+      uint32_t *SX = (uint32_t *)(S3 + n_chunks * 64), *MX = SX + n_chunks * 64;
+      int64_t o = c * 64 + lane;
+      S1[o] = a1;
+      S2[o] = a2;
+      S3[o] = a3;
+      SX[o] = acc;
+      MX[o] = acc >> 3;
+    }
   }
-  if (acc == 0x9e3779b9u || a1 + a2 + a3 == 0.123) sink[0] = acc;   // keeps the work alive, practically never taken
+  if (MODE != 3 && (acc == 0x9e3779b9u || a1 + a2 + a3 == 0.123)) sink[0] = acc;   // keeps the work alive, practically never taken
 }
 
 extern "C" {
 
 int mm_debug_read_probe(const void *d_src, int64_t n_bytes, int32_t n_workgroups, int32_t mode, uint32_t *d_sink, void *stream) {
-  MM_ARG(d_src && d_sink && n_bytes >= 65536 && n_workgroups > 0 && mode >= 0 && mode <= 2);
-  auto kern = mode == 0 ? k_read_probe<0> : (mode == 1 ? k_read_probe<1> : k_read_probe<2>);
+  MM_ARG(d_src && d_sink && n_bytes >= 65536 && n_workgroups > 0 && mode >= 0 && mode <= 3);
+  auto kern = mode == 0 ? k_read_probe<0> : (mode == 1 ? k_read_probe<1> : (mode == 2 ? k_read_probe<2> : k_read_probe<3>));
   hipLaunchKernelGGL(kern, dim3((unsigned)n_workgroups), dim3(1024), 0, (hipStream_t)stream, (const u32x4 *)d_src, n_bytes / 65536,
                      d_sink);
   MM_LAUNCH_CHECK();

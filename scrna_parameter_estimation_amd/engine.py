@@ -205,9 +205,7 @@ class CountBlocks:
         del blk_cnt
         # slab for K1 partial sums (reused across calls)
         n = max(1, self.total_items) * 64
-        self._S = [empty((n,), torch.float64) for _ in range(3)]
-        self._SX = empty((n,), torch.int32)
-        self._MX = empty((n,), torch.int32)
+        self._slab = empty((n * 8,), torch.int32)          # 32-byte record per (item, lane): S1, S2, S3 (fp64), sum x, max x
 
     @property
     def ent_bytes(self):
@@ -222,8 +220,7 @@ class CountBlocks:
     def launch_moments(self, d_inv_sf):
         """Enqueue only the K1 kernel (used by bench.py to time the roofline kernel)."""
         _lib.call("mm_moments1d_sell", P(self.ent), P(self.blk_base), P(self.slice_w), P(self.slice_ptr), P(self.item_ptr),
-                  P(self.blk_item_base), P(self.d_blk_cell0), P(d_inv_sf), self.n_blocks, self.G, P(self._S[0]), P(self._S[1]),
-                  P(self._S[2]), P(self._SX), P(self._MX), _stream())
+                  P(self.blk_item_base), P(self.d_blk_cell0), P(d_inv_sf), self.n_blocks, self.G, P(self._slab), _stream())
 
     def moments(self, inv_sf_cells):
         """K1+K2.  ``inv_sf_cells``: 1/size_factor per ORIGINAL cell index.  Returns host arrays
@@ -234,7 +231,7 @@ class CountBlocks:
         out_S = empty((3, self.n_groups, self.G), torch.float64)
         out_sx = empty((self.n_groups, self.G), torch.int64)
         out_mx = empty((self.n_groups, self.G), torch.int32)
-        _lib.call("mm_moments1d_reduce", P(self._S[0]), P(self._S[1]), P(self._S[2]), P(self._SX), P(self._MX), P(self.rank),
+        _lib.call("mm_moments1d_reduce", P(self._slab), P(self.rank),
                   P(self.item_ptr), P(self.blk_item_base), P(self.d_grp_blk0), self.n_groups, self.G, P(out_S), P(out_sx),
                   P(out_mx), _stream())
         return host(out_S), host(out_sx, np.uint64), host(out_mx, np.uint32)

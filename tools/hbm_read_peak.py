@@ -25,12 +25,12 @@ print(f"fill: {ms:.3f} ms -> {x.numel()*4/ms/1e6:.0f} GB/s write")
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scrna_parameter_estimation_amd import _lib, engine
-sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+sink = torch.zeros((x.numel() * 4 // 65536) * 64 * 8 + 16, dtype=torch.int32, device="cuda")     # mode 3 writes 32 B per (chunk, lane)
 nbytes = (x.numel() * 4 // 65536) * 65536
 timer = ctypes.c_void_p(); _lib.call("mm_timer_create", ctypes.byref(timer)); st = engine._stream()
 xr = torch.randint(0, 2 ** 31 - 1, (x.numel(),), dtype=torch.int32, device="cuda")      # random cell indices / counts for modes 1, 2
-for mode, what in ((0, "loads only"), (1, "+ LDS gather"), (2, "+ LDS gather + fp64 math")):
-    for wgs in (256, 1024, 2048):
+for mode, what in ((0, "loads only"), (1, "+ LDS gather"), (2, "+ LDS gather + fp64 math"), (3, "+ gather + math + result stores")):
+    for wgs in (256, 2048):
         for _ in range(3):
             _lib.call("mm_debug_read_probe", engine.P(xr), nbytes, wgs, mode, engine.P(sink), st)
         _lib.call("mm_timer_begin", timer, st)
