@@ -156,8 +156,13 @@ __global__ __launch_bounds__(K1_THREADS, K1_MIN_WAVES) void k_moments1d_sell(con
     r0v.z = (uint32_t)__double2loint(a2); r0v.w = (uint32_t)__double2hiint(a2);
     r1v.x = (uint32_t)__double2loint(a3); r1v.y = (uint32_t)__double2hiint(a3);
     r1v.z = sx; r1v.w = mx;
+#ifdef K1_NT_STORE
+    __builtin_nontemporal_store(r0v, rec);
+    __builtin_nontemporal_store(r1v, rec + 1);
+#else
     rec[0] = r0v;
     rec[1] = r1v;
+#endif
   }
 }
 
