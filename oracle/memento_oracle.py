@@ -426,13 +426,23 @@ def bootstrap_2d(v1, v2, approx_sf, q, num_boot, r, r0):
     return cov, var1, var2
 
 
-def regress_2d(cov_, trt, boot_corr, Nc, resampling="bootstrap", approx=False):
-    """_regress_2d without resample_rep (hypothesis_test.py:367-414)."""
+def regress_2d(cov_, trt, boot_corr, Nc, resampling="bootstrap", approx=False, resample_rep=False, drop_degenerate=False):
+    """_regress_2d (hypothesis_test.py:367-414); ``resample_rep`` draws from the global np.random stream like the
+    reference (:393-404)."""
     ok = np.all(np.isfinite(boot_corr), axis=0)
     bc = boot_corr[:, ok]
     Nc = np.asarray(Nc, dtype=np.float64)
     if (trt == 1).mean() == 1:
         cc = np.average(bc, axis=0, weights=Nc).reshape(1, -1)
+    elif resample_rep:
+        n, nb = bc.shape[0], bc.shape[1] - 1
+        bct = _sklearn_like_residualize(bc, cov_, Nc)
+        tt = _sklearn_like_residualize(trt, cov_, Nc)
+        ra = np.random.choice(n, size=(n, nb))
+        ra[:, 0] = np.arange(n)
+        ba = np.random.choice(nb, (n, nb)) + 1
+        ba[:, 0] = 0
+        cc = cross_coef_resampled(tt[ra], bct[(ra, ba)], Nc[ra], drop_degenerate)
     else:
         cc = cross_coef(_weighted_residualize(trt, cov_, Nc), _weighted_residualize(bc, cov_, Nc), Nc)
     asl = np.array([compute_asl(row, resampling, approx) for row in cc])

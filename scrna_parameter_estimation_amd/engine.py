@@ -744,6 +744,28 @@ class Bootstrap2D:
         self.active = active
         self.pair_slot = pair_slot
 
+    def contract_resampled(self, test_pair, tt, good, pair_mask, M, Nc, rep=None, bcol=None, seed=0):
+        """resample_rep=True on the correlation rows (hypothesis_test.py:393-404): residualise (copy), then the resampled
+        weighted slopes + null statistics.  Same kernels and conventions as Bootstrap1D.contract_resampled."""
+        torch = _torch()
+        s = _stream()
+        n_tests = len(test_pair)
+        yt = self.yc.clone()
+        d_pm, d_M = dev(np.asarray(pair_mask, dtype=np.int32)), dev(np.asarray(M, dtype=np.float64))
+        _lib.call("mm_residualize", P(yt), self.ld, self.ld, self.ng, self.n_q // self.ng, P(d_pm), P(d_M), s)
+        coef = empty((max(1, n_tests), self.ld), torch.float64)
+        stats = empty((max(1, n_tests), 8), torch.float64)
+        status = zeros((1,), torch.int32)
+        d_tp, d_tt, d_good = dev(np.asarray(test_pair, dtype=np.int32)), dev(np.asarray(tt, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
+        d_nc = dev(np.asarray(Nc, dtype=np.float64))
+        d_rep = dev(np.asarray(rep, dtype=np.int16)) if rep is not None else None
+        d_bcol = dev(np.asarray(bcol, dtype=np.int32)) if bcol is not None else None
+        _lib.call("mm_cross_resampled", P(yt), self.ld, self.B, self.ng, P(d_tp), P(d_tt), P(d_good), P(d_nc), P(d_rep), P(d_bcol),
+                  int(seed) & ((1 << 64) - 1), n_tests, P(coef), P(stats), P(status), s)
+        if int(status.item()) & 1:
+            raise NotImplementedError("resample_rep=True with non-finite replicate columns (the reference would drop them)")
+        return coef, host(stats)[:n_tests]
+
     def contract(self, test_pair, W, good):
         """K9/K10 on the correlation rows: tests (sorted pair index, weight row)."""
         torch = _torch()

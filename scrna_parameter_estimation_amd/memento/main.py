@@ -693,14 +693,17 @@ def get_corr_matrix(adata, group):
 
 
 def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=3, num_cpus=1,
-                  max_rows=None, **kwargs):
+                  max_rows=None, fill_seed=0, **kwargs):
     """Bootstrap hypothesis test of correlation differences (reference: memento/main.py:418-520,
-    hypothesis_test._ht_2d :303-364).  Same replay semantics as ht_1d_moments."""
+    hypothesis_test._ht_2d :303-364).  Same replay semantics as ht_1d_moments.  ``resample_rep=True``
+    (hypothesis_test.py:393-404): the group / replicate-column assignments are drawn on the device (seeded by
+    ``fill_seed``), i.e. statistically equivalent to the reference's np.random.choice draws, not draw-identical."""
     if 'resampling' not in kwargs:
         raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
-    if kwargs.get('resample_rep', False) or treatment_for_gene is not None:
-        raise NotImplementedError("HIP path (2D): resample_rep=False, treatment_for_gene=None")
+    if treatment_for_gene is not None:
+        raise NotImplementedError("HIP path (2D): treatment_for_gene=None (the reference's own lookup is broken, main.py:492)")
     resampling = kwargs['resampling']
+    resample_rep = bool(kwargs.get('resample_rep', False))
     approx = bool(kwargs.get('approx', False))
     if not inplace:
         adata = adata.copy()
@@ -766,6 +769,25 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             rows.append(W)
         Wmat = np.concatenate(rows, axis=0) if rows else np.zeros((0, ng))
         coef, stt = bs.contract(np.arange(n_ch), Wmat, good)
+        if resample_rep and n_ch:
+            # residual maker / residualised treatment per valid-group mask; an all-ones treatment keeps the weighted-average
+            # branch (hypothesis_test.py:384-386) and is not resampled
+            masks, pair_mask, tt_rows, rr_test, Ms = {}, np.zeros(n_ch, dtype=np.int32), [], np.zeros(n_ch, dtype=bool), []
+            for k in range(n_ch):
+                key = good[k].tobytes()
+                if key not in masks:
+                    Mg, ttg = _design.residual_parts(cov, trt, Nc_list, good[k])
+                    masks[key] = (len(Ms), ttg[:1], bool(good[k].any() and (trt[good[k]] == 1).mean() == 1))
+                    Ms.append(Mg)
+                pair_mask[k], ttg, allones = masks[key]
+                tt_rows.append(ttg)
+                rr_test[k] = good[k].any() and not allones
+            if rr_test.any():
+                coef_r, stt_r = bs.contract_resampled(np.arange(n_ch), np.concatenate(tt_rows, axis=0), good, pair_mask, np.stack(Ms),
+                                                      Nc_list, seed=fill_seed + 17 + lo)
+                stt = np.where(rr_test[:, None], stt_r, stt)
+                rr_idx = engine.dev(np.flatnonzero(rr_test))
+                coef[rr_idx] = coef_r[rr_idx]
         pvals = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus, resampling)
         for k in range(n_ch):
             c = int(first[lo + so[k]])

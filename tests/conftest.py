@@ -49,6 +49,11 @@ def internals_small():
 
 
 @pytest.fixture(scope="session")
+def regress2d_rr():
+    return load_golden("regress2d_rr")
+
+
+@pytest.fixture(scope="session")
 def regress_asl():
     return load_golden("regress_asl")
 

@@ -262,6 +262,25 @@ def perm_case(name, num_boot, ht_seed):
     print(name, "genes", len(out["gene_list"]), "finite p", np.isfinite(out["ht_exact_mean_asl"]).sum())
 
 
+def regress2d_rr_case(name, seed):
+    """_regress_2d with resample_rep=True (hypothesis_test.py:393-404) on synthetic replicate correlations: 6 groups
+    (2 conditions x 3 replicates), intercept + numeric covariate, binary treatment."""
+    rng = np.random.default_rng(seed)
+    ng, B = 6, 160
+    cov = np.column_stack([np.ones(ng), rng.normal(size=ng)])
+    trt = np.array([0, 0, 0, 1, 1, 1], dtype=float).reshape(-1, 1)
+    Nc = rng.integers(200, 900, size=ng).astype(float)
+    base = np.array([0.1, 0.12, 0.08, 0.35, 0.3, 0.4])
+    bc = base[:, None] + 0.05 * rng.normal(size=(ng, B + 1))
+    out = dict(cov=cov, trt=trt, Nc=Nc, boot_corr=bc, np_seed=np.int64(77))
+    for tag, approx in (("exact", False), ("approx", True)):
+        np.random.seed(77)
+        res = rht._regress_2d(cov, trt, bc.copy(), Nc, resample_rep=True, resampling="bootstrap", approx=approx)
+        out[f"coef_{tag}"], out[f"se_{tag}"], out[f"asl_{tag}"] = (np.asarray(x, dtype=float) for x in res[:3])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, out["coef_exact"], out["se_exact"], out["asl_exact"])
+
+
 def opts_case(name):
     """Non-default options the reference's analyses use a lot: setup_memento(filter_mean_thresh, trim_percent, shrinkage,
     num_bins), compute_1d_moments(filter_genes=False) and compute_1d_moments(gene_list=[...]).  Inputs = those of api_small."""
@@ -322,6 +341,9 @@ def opts_case(name):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["rr2d"]:
+        regress2d_rr_case("regress2d_rr", seed=13)
+        sys.exit(0)
     if sys.argv[1:] == ["opts"]:
         opts_case("api_opts")
         sys.exit(0)
@@ -338,3 +360,4 @@ if __name__ == "__main__":
     regress_asl_case("regress_asl", seed=5)
     perm_case("api_perm", num_boot=300, ht_seed=21)
     opts_case("api_opts")
+    regress2d_rr_case("regress2d_rr", seed=13)

@@ -203,6 +203,57 @@ def test_ht_2d_is_independent_of_the_packing(api_small, monkeypatch):
     assert np.isfinite(res[0][3]).mean() > 0.9
 
 
+def test_2d_resample_rep_kernels_match_reference(regress2d_rr):
+    """resample_rep=True on correlation rows: mm_residualize + mm_cross_resampled fed with the reference's own np.random.choice
+    draws reproduce _regress_2d(resample_rep=True) of the REAL reference (fixture regress2d_rr: coefficient, SE, p-values)."""
+    import torch
+
+    from scrna_parameter_estimation_amd import engine
+    from scrna_parameter_estimation_amd.memento import asl, design
+
+    r = regress2d_rr
+    bc, cov, trt, Nc = r["boot_corr"], r["cov"], r["trt"], r["Nc"]
+    ng, B = bc.shape[0], bc.shape[1] - 1
+    np.random.seed(int(r["np_seed"]))                     # the two draws of hypothesis_test.py:395-398
+    ra = np.random.choice(ng, size=(ng, B)); ra[:, 0] = np.arange(ng)
+    ba = np.random.choice(B, (ng, B)) + 1; ba[:, 0] = 0
+    bs = object.__new__(engine.Bootstrap2D)               # only the replicate rows and their shape are needed here
+    bs.yc, bs.ld, bs.B, bs.ng, bs.n_q = engine.dev(bc.copy()), B + 1, B, ng, ng
+    good = np.ones((1, ng), dtype=bool)
+    M, tt = design.residual_parts(cov, trt, Nc, good[0])
+    coef, st = bs.contract_resampled(np.arange(1), tt[:1], good, np.zeros(1, np.int32), M[None], Nc, rep=ra[None].astype(np.int16),
+                                     bcol=ba[None].astype(np.int32))
+    np.testing.assert_allclose(st[0, 0], r["coef_exact"][0], rtol=1e-9)
+    np.testing.assert_allclose(st[0, 1], r["se_exact"][0], rtol=1e-7)
+    rows = engine.host(coef)
+    for tag, approx in (("exact", False), ("approx", True)):
+        p = asl.asl_from_stats(st, approx, lambda idx: rows[idx], num_cpus=1)
+        np.testing.assert_allclose(p[0], r[f"asl_{tag}"][0], rtol=1e-5)
+
+
+def test_ht_2d_resample_rep_api(api_small):
+    """ht_2d_moments(resample_rep=True): assignments are drawn on the device, so coefficients equal the plain run's exactly and
+    the standard errors / p-values are those of a different (hierarchical) null -- same order of magnitude, finite."""
+    g = api_small
+    memento, adata = _run_to_moments(g)
+    names = np.asarray(adata.var.index)
+    pairs = list(zip(names[g["pair_idx1"]].tolist(), names[g["pair_idx2"]].tolist()))
+    memento.compute_2d_moments(adata, pairs)
+    cov, trt = _design(memento, adata, g)
+    res = {}
+    for rr in (False, True):
+        np.random.seed(11)
+        memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=300, num_cpus=1, verbose=0, resampling="bootstrap",
+                              approx=True, resample_rep=rr)
+        ht = adata.uns["memento"]["2d_ht"]
+        res[rr] = (ht["corr_coef"].copy(), ht["corr_se"].copy(), ht["corr_asl"].copy())
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-9, equal_nan=True)
+    fin = np.isfinite(res[False][1])
+    assert np.isfinite(res[True][1][fin]).all() and np.isfinite(res[True][2][fin]).all()
+    ratio = res[True][1][fin] / res[False][1][fin]
+    assert 0.3 < np.median(ratio) < 3.0
+
+
 def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     """strict=False: identical multinomial replay, but invalid replicates are refilled on the device with a
     counter-based RNG -> observed coefficients identical, SEs/p-values agree within Monte-Carlo error and

@@ -151,3 +151,15 @@ def test_ht_1d_permutation_resampling(api_small, api_perm, tag, approx, off):
                     g["group_q"], resampling="permutation", approx=approx)
     for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], out):
         np.testing.assert_allclose(v, gp[f"ht_{tag}_{k}"], rtol=1e-7, equal_nan=True, err_msg=k)
+
+
+@pytest.mark.parametrize("tag,approx", [("exact", False), ("approx", True)])
+def test_regress_2d_resample_rep(regress2d_rr, tag, approx):
+    """_regress_2d with resample_rep=True (hypothesis_test.py:393-404), replaying the reference's np.random.choice draws
+    (6 groups: no resampled column is degenerate in this fixture, so the agreement is exact)."""
+    r = regress2d_rr
+    np.random.seed(int(r["np_seed"]))
+    coef, se, asl = orc.regress_2d(r["cov"], r["trt"], r["boot_corr"], r["Nc"], resampling="bootstrap", approx=approx, resample_rep=True)
+    np.testing.assert_allclose(coef, r[f"coef_{tag}"], rtol=1e-9)
+    np.testing.assert_allclose(se, r[f"se_{tag}"], rtol=1e-7)
+    np.testing.assert_allclose(asl, r[f"asl_{tag}"], rtol=1e-7)
