@@ -258,8 +258,10 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
     K_max(lanes) x c(L), c(L) = C0 + C1*L per bin step (lanes diverge between the inversion and BTPE samplers and every
     data-dependent loop runs for the slowest lane).  Wide waves are the most instruction-efficient, but the heaviest chain
     bounds the makespan; so every wave gets the same cost budget: L(K) = largest lane count with K*c(L) <= budget, and the
-    budget is chosen (bisection) to yield about ``target_waves`` waves.  ``dense``: plain 64-wide tiles (fast mode: one
-    wave per chain, lanes = replicates).  Returns (slot of every chain = tile*64 + lane, number of tiles)."""
+    budget is chosen (bisection) to yield about ``target_waves`` waves, all resident at once ("resident" packing).  With very
+    many chains a second, work-bound packing (see below) is built as well and the one with the shorter predicted run time
+    is returned.  ``dense``: plain 64-wide tiles (fast mode: one wave per chain, lanes = replicates).
+    Returns (slot of every chain = tile*64 + lane, number of tiles)."""
     Ks = np.maximum(np.asarray(K_sorted_desc, dtype=np.float64), 1.0)
     n_act = len(Ks)
     if n_act == 0:
