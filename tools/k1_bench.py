@@ -22,3 +22,15 @@ ms = ctypes.c_float(); _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(ms))
 nb = blocks.moments_bytes()
 print(f"defs={os.environ.get('MM_EXTRA_DEFS','')!r} nnz={csr.nnz:.3e} blocks={blocks.n_blocks} items={blocks.total_items} ent={blocks.ent_bytes/1e9:.3f}GB "
       f"pad={blocks.ent_bytes/4/max(1,blocks.nnz_sel):.3f} bytes={nb/1e9:.3f}GB  K1={ms:.4f} ms  {nb/ms/1e6:.1f} GB/s  ({nb/ms/1e6/8000:.1%} of 8TB/s)  gen={t_gen:.1f}s ingest={t_ing:.2f}s", flush=True)
+# clocks of this box while the kernel runs (boxes of the pool differ by ~10 % on K1): sample rocm-smi from a helper process
+import subprocess, threading
+def _spin():
+    for _ in range(4000): blocks.launch_moments(d_inv)
+    torch.cuda.synchronize()
+th = threading.Thread(target=_spin); th.start(); time.sleep(0.5)
+try:
+    out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=30).stdout
+    print(" | ".join(l.split(":", 1)[1].strip() if ":" in l else l for l in out.splitlines() if any(k in l for k in ("fclk", "mclk", "sclk", "Power (W)"))), flush=True)
+except Exception as e:
+    print("rocm-smi unavailable:", e)
+th.join()
