@@ -45,10 +45,22 @@ __global__ __launch_bounds__(K1_THREADS, K1_MIN_WAVES) void k_moments1d_sell(con
                                                                const int32_t *__restrict__ slice_w, const int32_t *__restrict__ slice_ptr,
                                                                const int32_t *__restrict__ item_ptr, const int64_t *__restrict__ blk_item_base,
                                                                const int32_t *__restrict__ blk_cell0, const double *__restrict__ inv_sf,
-                                                               int32_t n_slices, int32_t split, u32x4 *__restrict__ slab) {
+                                                               int32_t n_slices, int32_t split, int32_t n_wg, u32x4 *__restrict__ slab) {
   __shared__ double w_lds[MM_BLOCK_CELLS];
   __shared__ int32_t ip[K1_MAX_SLICES + 1], sp[K1_MAX_SLICES + 1], sw[K1_MAX_SLICES];
-  int b = blockIdx.x / split, part = blockIdx.x % split;
+#ifndef K1_XCD_REMAP
+#define K1_XCD_REMAP 1
+#endif
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Renumber them so that the `split`
+  // workgroups of one count block run on ONE XCD: its 1/size-factor vector and slice tables are then fetched into one L2
+  // instead of eight.  The grid is padded to a multiple of 8; ids past the real count exit.
+  int wg = blockIdx.x;
+  if (K1_XCD_REMAP) {
+    int per = gridDim.x >> 3;
+    wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  }
+  if (wg >= n_wg) return;
+  int b = wg / split, part = wg % split;
   int c0 = blk_cell0[b], nc = blk_cell0[b + 1] - c0;
   for (int i = threadIdx.x; i < MM_BLOCK_CELLS; i += K1_THREADS) w_lds[i] = i < nc ? inv_sf[c0 + i] : 0.0;
   // the block's slice tables go to LDS too: the item -> slice lookup must not be a chain of global loads
@@ -215,9 +227,10 @@ int mm_moments1d_sell(const uint32_t *d_ent, const int64_t *d_blk_base, const in
   int split = (K1_WGS + n_blocks - 1) / n_blocks;
   if (split < 1) split = 1;
   if (split > 64) split = 64;
-  hipLaunchKernelGGL(k_moments1d_sell, dim3((unsigned)(n_blocks * split)), dim3(K1_THREADS), 0, (hipStream_t)stream,
+  int n_wg = n_blocks * split;
+  hipLaunchKernelGGL(k_moments1d_sell, dim3((unsigned)((n_wg + 7) / 8 * 8)), dim3(K1_THREADS), 0, (hipStream_t)stream,
                      (const u32x4 *)d_ent, d_blk_base, d_slice_w, d_slice_ptr, d_item_ptr, d_blk_item_base, d_blk_cell0, d_inv_sf,
-                     n_slices, split, (u32x4 *)d_slab);
+                     n_slices, split, n_wg, (u32x4 *)d_slab);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -13,7 +13,7 @@ gid = np.random.default_rng(0).integers(0, groups, size=cells).astype(np.int32)
 t0 = time.time(); blocks = engine.CountBlocks(csr, gid, groups); torch.cuda.synchronize(); t_ing = time.time() - t0
 d_inv = engine.dev(np.random.default_rng(1).lognormal(0, .3, size=cells)[blocks.cell_order])
 timer = ctypes.c_void_p(); _lib.call("mm_timer_create", ctypes.byref(timer)); s = engine._stream()
-for _ in range(3): blocks.launch_moments(d_inv)
+for _ in range(100): blocks.launch_moments(d_inv)      # sustained rate: the first ~40 launches after idle are 5-20 % slower
 reps = 20
 _lib.call("mm_timer_begin", timer, s)
 for _ in range(reps): blocks.launch_moments(d_inv)
