@@ -160,21 +160,17 @@ __global__ __launch_bounds__(K1_THREADS, K1_MIN_WAVES) void k_moments1d_sell(con
         }
       }
     }
-    // one 32-byte record per (item, lane): {S1, S2 | S3, sum x, max x}; a wave writes ONE contiguous 2 KiB run (two dwordx4
-    // stores per lane).  Five separate result arrays cost 10 % of the kernel for 3 % of its bytes (tools/hbm_read_peak.py, mode 3)
+    // one 32-byte record per (item, lane): {S1, S2 | S3, sum x, max x}; a wave writes ONE contiguous 2 KiB run per work item
+    // (two dwordx4 stores per lane).  Exchanging words between lanes so that each store instruction covers a fully contiguous
+    // 1 KiB was measured too: 1.4 % slower (profiles/README.md).
     u32x4 *rec = slab + ((ibase + item) * 64 + lane) * 2;
     u32x4 r0v, r1v;
     r0v.x = (uint32_t)__double2loint(a1); r0v.y = (uint32_t)__double2hiint(a1);
     r0v.z = (uint32_t)__double2loint(a2); r0v.w = (uint32_t)__double2hiint(a2);
     r1v.x = (uint32_t)__double2loint(a3); r1v.y = (uint32_t)__double2hiint(a3);
     r1v.z = sx; r1v.w = mx;
-#ifdef K1_NT_STORE
-    __builtin_nontemporal_store(r0v, rec);
-    __builtin_nontemporal_store(r1v, rec + 1);
-#else
     rec[0] = r0v;
     rec[1] = r1v;
-#endif
   }
 }
 
