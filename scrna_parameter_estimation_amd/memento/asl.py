@@ -112,13 +112,15 @@ class _main_hidden:
         return False
 
 
-def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1, resampling='bootstrap'):
+def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1, resampling='bootstrap', defer=False):
     """Vector of ASLs for all tests.
 
     ``stats_arr`` [n_tests][8] = {coef0, se, n_valid, extreme_count, null_mean, all_equal, extreme_count_raw, range}
     (include/memento_hip.h); ``fetch_rows(idx)`` returns the coefficient rows (host, [len(idx)][B+1]) of the tests that
     need a tail fit.  ``resampling``: 'bootstrap' centres the null on the observed value, anything else does not
     (hypothesis_test.py:66-70) -- the replicates themselves are the same bootstrap either way.
+    ``defer``: return a function that yields the vector instead -- the tail fits are already running in the worker pool,
+    so the caller can enqueue more device work (and more fits) before collecting them.
     """
     st = np.asarray(stats_arr)
     coef0, se, n, c, nmean, alleq = st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], st[:, 5]
@@ -131,18 +133,23 @@ def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1, resampling='bootst
         a = np.abs(coef0[live])
         with np.errstate(invalid="ignore", divide="ignore"):
             asl[live] = stats.norm.sf(a, nmean[live], se[live]) + stats.norm.cdf(-a, nmean[live], se[live])
-        return asl
+        return (lambda: asl) if defer else asl
     big = live & (c > 10)
     asl[big] = (c[big] + 1) / (n[big] + 1)
     need = np.flatnonzero(live & (c <= 10))
+    it = None
     if len(need):
         rows = fetch_rows(need)
         jobs = [(rows[i], float(c[t]), centred) for i, t in enumerate(need)]
         if num_cpus and num_cpus > 1 and len(jobs) > 1:
             with _main_hidden():        # workers are spawned on submit
                 it = get_pool(num_cpus).map(_tail_job, jobs, chunksize=max(1, len(jobs) // (4 * num_cpus)))
-            res = list(it)
         else:
-            res = [tail_fit_asl(*j) for j in jobs]
-        asl[need] = res
-    return asl
+            it = (tail_fit_asl(*j) for j in jobs)
+
+    def finish():
+        if it is not None:
+            asl[need] = list(it)
+        return asl
+
+    return finish if defer else finish()

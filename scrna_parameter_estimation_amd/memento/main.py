@@ -511,9 +511,16 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 coef[rr_idx] = coef_r[rr_idx]
             no_group = ~good[np.asarray(test_gene, dtype=np.int64)].any(axis=1) if n_tests else np.zeros(0, bool)
             c0, se = stt[:, 0].copy(), stt[:, 1].copy()
-            p = _asl.asl_from_stats(stt, approx, lambda idx: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]), num_cpus, resampling)
-            c0[no_group], se[no_group], p[no_group] = np.nan, np.nan, np.nan                              # hypothesis_test.py:203-204
-            out[tag + '_coef'], out[tag + '_se'], out[tag + '_asl'] = c0, se, p
+            # the tail fits of the mean tests run in the worker pool while the variance contraction is enqueued
+            fin = _asl.asl_from_stats(stt, approx, lambda idx, coef=coef: engine.host(coef[engine.dev(np.asarray(idx, dtype=np.int64))]),
+                                      num_cpus, resampling, defer=True)
+            c0[no_group], se[no_group] = np.nan, np.nan                                                   # hypothesis_test.py:203-204
+            out[tag + '_coef'], out[tag + '_se'], out[tag + '_asl'] = c0, se, (fin, no_group)
+        for tag in ('mean', 'var'):
+            fin, no_group = out[tag + '_asl']
+            p = fin()
+            p[no_group] = np.nan
+            out[tag + '_asl'] = p
         st.last_bootstrap = bs
         st.last_assignments = (rep_assign, bcol_assign)
         return out
