@@ -49,7 +49,8 @@ def main():
     pk = engine.host(bs._ops[0]).reshape(-1, 64)
     simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
     uid = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
-    print(f"{name}: run {dt:.2f}s, tiles {nt}, kernel span {(end.max()-t_first)/1e8:.2f}s")
+    print(f"{name}: run {dt:.2f}s, tiles {nt}, kernel span {(end.max()-t_first)/1e8:.2f}s; packing {engine.PACK_LAST.get('chosen')}, "
+          f"K mean {bs.K[bs.K >= 2].mean():.0f} max {bs.K.max()}")
     print("wave duration s: min %.2f p10 %.2f median %.2f p90 %.2f max %.2f ; sum %.1f" % (dur.min(), *np.quantile(dur, [.1, .5, .9]), dur.max(), dur.sum()))
     print("start offsets s: max %.3f ; waves starting later than 0.1 s: %d" % ((start.max() - t_first) / 1e8, ((start - t_first) / 1e8 > 0.1).sum()))
     u, inv = np.unique(uid, return_inverse=True)
