@@ -190,18 +190,26 @@ int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_
                       int64_t n_tests, int32_t which, double *d_coef, double *d_stats, void *stream);
 
 /* ---- resample_rep=True: hierarchical resampling of replicate groups ------------------------------------
- * replaces hypothesis_test._regress_1d :273-286 and _cross_coef_resampled :231-239.
- * mm_residualize: in place y~ = M y on the [n_genes*n_groups][ld] rows (columns 0..n_cols-1); gene g uses the
- * n_groups x n_groups matrix d_M[d_gene_mask[g]] (zero rows/columns on invalid groups -> NaN rows). */
-int mm_residualize(double *d_y, int64_t ld, int32_t n_cols, int32_t n_groups, int32_t n_genes, const int32_t *d_gene_mask,
-                   const double *d_M, void *stream);
-/* mm_cross_resampled: coefficient of resampled column c < num_boot (column 0 = observed).  d_tt[test][group] =
- * residualised treatment; d_rep/d_bcol [gene][n_groups][num_boot] = group index (into the gene's valid groups) and
- * replicate column drawn for row i of column c (np.random.choice replay), or both NULL to draw them on the device.
- * d_status |= 1 if a gathered value is not finite (the reference would have dropped that replicate column). */
+ * replaces hypothesis_test._regress_1d :249-254, :273-286, _regress_2d :372-377, :393-404 and _cross_coef_resampled :231-239.
+ * mm_valid_cols: the replicate columns that survive valid_boostrap_iters (:249-251): d_col_map[gene][k] = k-th column in
+ * which every good group is finite in BOTH d_ym and d_yv (pass the same pointer twice for the 2D correlation rows),
+ * d_n_valid[gene] = their number.  d_col_map is [n_genes][num_boot + 1].
+ * mm_residualize: d_dst = M d_src on the [n_genes*n_groups][ld] rows (columns 0..n_cols-1; d_dst must not alias d_src);
+ * gene g uses the n_groups x n_groups matrix d_M[d_gene_mask[g]] (zero rows/columns on invalid groups -> NaN rows).
+ * Any number of groups (one group per donor: analysis/lupus/run_memento.py:31-52). */
+int mm_valid_cols(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups, const uint8_t *d_good,
+                  int64_t n_genes, int32_t *d_col_map, int32_t *d_n_valid, void *stream);
+int mm_residualize(const double *d_src, double *d_dst, int64_t ld, int32_t n_cols, int32_t n_groups, int64_t n_genes,
+                   const int32_t *d_gene_mask, const double *d_M, void *stream);
+/* mm_cross_resampled: coefficient of resampled column c < nb (column 0 = observed), nb = d_n_valid[gene] - 1 (num_boot when
+ * d_col_map / d_n_valid are NULL).  d_tt[test][group] = residualised treatment; d_rep/d_bcol [gene][n_groups][num_boot] =
+ * group index (into the gene's valid groups) and index (1..nb, into the surviving columns) of the replicate column drawn for
+ * row i of column c (np.random.choice replay), or both NULL to draw them on the device.  Columns whose drawn groups all share
+ * one treatment value (0/0 in the reference) are reported as NaN. */
 int mm_cross_resampled(const double *d_yt, int64_t ld, int32_t num_boot, int32_t n_groups, const int32_t *d_test_gene,
                        const double *d_tt, const uint8_t *d_good, const double *d_Nc, const int16_t *d_rep, const int32_t *d_bcol,
-                       uint64_t seed, int64_t n_tests, double *d_coef, double *d_stats, int32_t *d_status, void *stream);
+                       const int32_t *d_col_map, const int32_t *d_n_valid, uint64_t seed, int64_t n_tests, double *d_coef,
+                       double *d_stats, void *stream);
 
 /* ---- two-group contrasts against a shared control (Perturb-seq batching) ---------------------
  * test t: coef_b = y[test_gene[t], test_grp[t]][b] - y[test_gene[t], ctrl][b] -- what _regress_1d computes for the two

@@ -390,11 +390,14 @@ def corr_matrix(X, size_factor, q, var):
     prod[d, d] -= (1 - q) * np.asarray(X.T.dot(w ** 2)).ravel() / n
     mu = np.asarray(Xw.mean(axis=0)).ravel()
     cov = prod - np.outer(mu, mu)
-    v = np.where(var <= 0, np.nan, var)
-    vp = np.sqrt(np.outer(v, v))
+    # estimator.py:259-263: the NaN assignments go to fancy-index COPIES (var_1, var_2); var_prod is built from the
+    # untouched ``var``, so two negative variances give a finite product, a negative x positive one sqrt(<0) = NaN
+    with np.errstate(invalid="ignore"):
+        vp = np.sqrt(np.outer(var, var))
     corr = np.full(cov.shape, 5.0)
     ok = np.isfinite(vp)
-    corr[ok] = cov[ok] / vp[ok]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        corr[ok] = cov[ok] / vp[ok]
     inside = (corr < 1.05) & (corr > -1.05)
     corr[inside] = np.clip(corr[inside], -1, 1)
     corr[(corr > 1) | (corr < -1)] = np.nan

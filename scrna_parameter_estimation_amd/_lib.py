@@ -58,9 +58,10 @@ _SIGS = {
                            c_void_p], ctypes.c_int),
     "mm_contrast_rows": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p],
                          ctypes.c_int),
-    "mm_residualize": ([c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "mm_cross_resampled": ([c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
-                            c_int64, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_valid_cols": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_residualize": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_cross_resampled": ([c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_extract_cols": ([c_void_p] * 6 + [c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_pair_cross": ([c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                        c_void_p, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),

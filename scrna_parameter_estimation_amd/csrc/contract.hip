@@ -133,35 +133,84 @@ __global__ __launch_bounds__(K9_THREADS) void k_contract_stats(const double *__r
 
 // ------------------------------------------------------------------------------------------------
 // resample_rep=True (hypothesis_test.py:273-286, :231-239): hierarchical resampling of the replicate groups.
-// Step 1: residualise the rows of a gene on the covariates, y~ = M y  (M = I - H of the weighted fit, zero on bad
-// groups), column by column (one thread owns a column, so it can run in place on a scratch copy).
-__global__ __launch_bounds__(256) void k_residualize(double *__restrict__ y, int64_t ld, int32_t n_cols, int32_t n_groups,
+// Step 0: which replicate columns survive hypothesis_test.py:249-251 (a column is dropped when ANY good group has a
+// non-finite mean OR variance entry).  One workgroup per gene: col_map[gene][k] = k-th surviving column (ascending),
+// n_valid[gene] = how many.  With nothing dropped col_map is the identity and n_valid = num_boot + 1.
+__global__ __launch_bounds__(256) void k_valid_cols(const double *__restrict__ ym, const double *__restrict__ yv, int64_t ld,
+                                                    int32_t num_boot, int32_t n_groups, const uint8_t *__restrict__ good,
+                                                    int32_t *__restrict__ col_map, int32_t *__restrict__ n_valid) {
+  extern __shared__ int32_t glist_v[];             // [n_groups] indices of good groups
+  __shared__ int n_good_s, base_s;
+  __shared__ int wave_cnt[4];
+  int64_t gene = blockIdx.x;
+  const uint8_t *gd = good + gene * n_groups;
+  if (threadIdx.x == 0) {
+    int ng = 0;
+    for (int j = 0; j < n_groups; j++)
+      if (gd[j]) glist_v[ng++] = j;
+    n_good_s = ng;
+    base_s = 0;
+  }
+  __syncthreads();
+  int n_good = n_good_s;
+  int n_cols = num_boot + 1;
+  int32_t *cm = col_map + gene * (int64_t)n_cols;
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < n_cols; c0 += 256) {
+    int c = c0 + threadIdx.x;
+    bool ok = c < n_cols;
+    if (ok) {
+      for (int q = 0; q < n_good; q++) {
+        int64_t o = (gene * n_groups + glist_v[q]) * ld + c;
+        ok = ok && isfinite(ym[o]) && isfinite(yv[o]);
+      }
+    }
+    uint64_t bal = __ballot(ok);
+    int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wv; w++) off += wave_cnt[w];
+    if (ok) cm[off + before] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_valid[gene] = base_s;
+}
+
+// Step 1: residualise the rows of a gene on the covariates, dst = M src  (M = I - H of the weighted fit, zero on bad
+// groups), column by column.  Any number of groups (one group per donor is the reference's real use of resample_rep,
+// analysis/lupus/run_memento.py:31-52): row i of M is staged in LDS, the column entries come back from L1/L2.
+// The sum runs over j in ascending order and skips exact zeros of M (rows that are all zero, i.e. bad groups, give NaN).
+__global__ __launch_bounds__(256) void k_residualize(const double *__restrict__ src, double *__restrict__ dst, int64_t ld,
+                                                     int32_t n_cols, int32_t n_groups, int32_t col_tiles,
                                                      const int32_t *__restrict__ gene_mask /* [n_genes] index into M */,
                                                      const double *__restrict__ M /* [n_masks][ng][ng] */) {
-  extern __shared__ double sm[];
-  int gene = blockIdx.y;
+  extern __shared__ double mrow[];                 // [n_groups]
+  int64_t gene = blockIdx.x / col_tiles;
+  int tile = (int)(blockIdx.x % col_tiles);
   const double *Mg = M + (int64_t)gene_mask[gene] * n_groups * n_groups;
-  for (int i = threadIdx.x; i < n_groups * n_groups; i += blockDim.x) sm[i] = Mg[i];
-  __syncthreads();
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_cols) return;
-  double *base = y + (int64_t)gene * n_groups * ld + c;
-  double in[64], out[64];
-  if (n_groups > 64) return;
-  for (int j = 0; j < n_groups; j++) in[j] = base[(int64_t)j * ld];
+  int c = tile * 256 + threadIdx.x;
+  bool mine = c < n_cols;
+  const double *sb = src + gene * n_groups * ld + c;
+  double *db = dst + gene * n_groups * ld + c;
   for (int i = 0; i < n_groups; i++) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_groups; j += 256) mrow[j] = Mg[(int64_t)i * n_groups + j];
+    __syncthreads();
+    if (!mine) continue;
     double acc = 0.0;
     bool any = false;
     for (int j = 0; j < n_groups; j++) {
-      double m = sm[i * n_groups + j];
+      double m = mrow[j];
       if (m != 0.0) {
-        acc += m * in[j];
+        acc += m * sb[(int64_t)j * ld];
         any = true;
       }
     }
-    out[i] = any ? acc : NAN;
+    db[(int64_t)i * ld] = any ? acc : NAN;
   }
-  for (int i = 0; i < n_groups; i++) base[(int64_t)i * ld] = out[i];
 }
 
 __device__ __forceinline__ uint64_t rr_mix(uint64_t x) {
@@ -171,17 +220,18 @@ __device__ __forceinline__ uint64_t rr_mix(uint64_t x) {
   return x ^ (x >> 31);
 }
 
-// Step 2: per test and resampled column c < num_boot: rows i = 0..n-1 take group rep[i][c] and replicate column
-// bcol[i][c] of the residualised response; coefficient = weighted slope on the residualised treatment of the drawn
-// groups (_cross_coef_resampled).  rep/bcol NULL -> drawn on the fly from a counter-based RNG (column 0 is always the
-// identity / observed column).  Then the same null statistics as k_contract_stats.
+// Step 2: per test and resampled column c < nb (nb = surviving columns - 1, hypothesis_test.py:249-254): rows i = 0..n-1 take
+// group rep[i][c] and the bcol[i][c]-th SURVIVING replicate column of the residualised response; coefficient = weighted slope
+// on the residualised treatment of the drawn groups (_cross_coef_resampled).  rep/bcol NULL -> drawn on the fly from a
+// counter-based RNG (column 0 is always the identity / observed column).  rep/bcol rows have stride num_boot.  Then the same
+// null statistics as k_contract_stats.
 __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__restrict__ yt, int64_t ld, int32_t num_boot,
                                                                 int32_t n_groups, const int32_t *__restrict__ test_gene,
                                                                 const double *__restrict__ tt /* [n_tests][ng] residualised treatment */,
                                                                 const uint8_t *__restrict__ good, const double *__restrict__ Nc,
                                                                 const int16_t *__restrict__ rep, const int32_t *__restrict__ bcol,
-                                                                uint64_t seed, double *__restrict__ coef, double *__restrict__ stats,
-                                                                int32_t *__restrict__ status) {
+                                                                const int32_t *__restrict__ col_map, const int32_t *__restrict__ n_valid,
+                                                                uint64_t seed, double *__restrict__ coef, double *__restrict__ stats) {
   extern __shared__ double sm[];
   double *tts = sm;                               // [ng]
   double *ncs = sm + n_groups;                    // [ng]
@@ -215,9 +265,18 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
   }
   const int16_t *rg = rep ? rep + (int64_t)gene * n_groups * num_boot : nullptr;
   const int32_t *bg = bcol ? bcol + (int64_t)gene * n_groups * num_boot : nullptr;
+  // surviving replicate columns (hypothesis_test.py:249-254): nb resampled columns, indices through col_map
+  const int32_t *cm = col_map ? col_map + (int64_t)gene * (num_boot + 1) : nullptr;
+  const int nb = n_valid ? n_valid[gene] - 1 : num_boot;
+  if (nb < 1) {    // nothing (or only one column) survives: the reference returns NaNs ("skipped") or has no null at all
+    for (int c = threadIdx.x; c <= num_boot; c += K9_THREADS) crow[c] = NAN;
+    if (threadIdx.x == 0) {
+      st[0] = NAN; st[1] = NAN; st[2] = 0; st[3] = 0; st[4] = NAN; st[5] = 0; st[6] = NAN; st[7] = NAN;
+    }
+    return;
+  }
   double s_sum = 0.0, s_cnt = 0.0, s_min = INFINITY, s_max = -INFINITY;
-  bool bad = false;
-  for (int c = threadIdx.x; c < num_boot; c += K9_THREADS) {
+  for (int c = threadIdx.x; c < nb; c += K9_THREADS) {
     double sw = 0.0, swy = 0.0, swa = 0.0, amax = 0.0;
     // first pass: weighted means
     for (int i = 0; i < n; i++) {
@@ -227,12 +286,12 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
       else {
         uint64_t h = rr_mix(seed ^ rr_mix(((uint64_t)gene << 32) ^ ((uint64_t)i << 24) ^ (uint64_t)c));
         r = (int)(h % (uint64_t)n);
-        bb = (int)(rr_mix(h) % (uint64_t)num_boot) + 1;
+        bb = (int)(rr_mix(h) % (uint64_t)nb) + 1;
       }
+      if (cm) bb = cm[bb];
       int j = glist[r];
       double y = yt[(row_base + j) * ld + bb];
       double w = ncs[j];
-      if (!isfinite(y)) bad = true;
       sw += w; swy += w * y; swa += w * tts[j];
       amax = fmax(amax, fabs(tts[j]));
     }
@@ -245,18 +304,20 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
       else {
         uint64_t h = rr_mix(seed ^ rr_mix(((uint64_t)gene << 32) ^ ((uint64_t)i << 24) ^ (uint64_t)c));
         r = (int)(h % (uint64_t)n);
-        bb = (int)(rr_mix(h) % (uint64_t)num_boot) + 1;
+        bb = (int)(rr_mix(h) % (uint64_t)nb) + 1;
       }
+      if (cm) bb = cm[bb];
       int j = glist[r];
       double y = yt[(row_base + j) * ld + bb];
       double w = ncs[j], da = tts[j] - mA;
       ss += da * da * w;
       num += (da * w) * (y - mB);
     }
-    // Degenerate column: every drawn group has the same (residualised) treatment, so the slope is 0/0.  The reference
-    // gets NaN there when its weighted mean happens to round to exactly that value and O(1) rounding noise otherwise
-    // (hypothesis_test.py:234-239 -- a ratio of two round-off residues); here such a column is always NaN, which
-    // np.nanstd and the isfinite filter of _compute_asl ignore.
+    // DELIBERATE DEVIATION: a degenerate column -- every drawn group has the same (residualised)
+    // treatment, so the slope is 0/0.  The reference gets NaN there when its weighted mean happens to round to exactly that
+    // value and O(1) noise otherwise (hypothesis_test.py:234-239: a ratio of two round-off residues, one of which comes out of
+    // LAPACK's least-squares residuals and is not reproducible bit for bit); here such a column is always NaN, which np.nanstd
+    // and the isfinite filter of _compute_asl ignore.  With >= 12 groups such columns do not occur (P < 1e-3 per column).
     double val = num / sw / (ss / sw);
     if (ss / sw <= 1e-24 * amax * amax) val = NAN;
     crow[c] = val;
@@ -269,8 +330,7 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
       }
     }
   }
-  if (threadIdx.x == 0) crow[num_boot] = NAN;  // the row has ld = num_boot + 1 slots; the resampled row uses num_boot
-  if (bad) atomicOr(status, 1);
+  for (int c = nb + threadIdx.x; c <= num_boot; c += K9_THREADS) crow[c] = NAN;  // the resampled row uses nb <= num_boot slots
   double tot = wg_sum(s_sum, red);
   double cnt = wg_sum(s_cnt, red);
   double mn = wg_min(s_min, red);
@@ -281,7 +341,7 @@ __global__ __launch_bounds__(K9_THREADS) void k_cross_resampled(const double *__
   double mean1 = cnt > 0 ? tot / cnt : NAN;
   double a0 = fabs(c0);
   double s_sq = 0.0, s_ext = 0.0, s_raw = 0.0;
-  for (int c = 1 + threadIdx.x; c < num_boot; c += K9_THREADS) {
+  for (int c = 1 + threadIdx.x; c < nb; c += K9_THREADS) {
     double val = crow[c];
     if (val == val) {
       double d = val - mean1;
@@ -405,26 +465,43 @@ int mm_contract_stats(const double *d_ym, const double *d_yv, int64_t ld, int32_
   return MM_OK;
 }
 
-int mm_residualize(double *d_y, int64_t ld, int32_t n_cols, int32_t n_groups, int32_t n_genes, const int32_t *d_gene_mask,
-                   const double *d_M, void *stream) {
-  MM_ARG(d_y && d_gene_mask && d_M && n_cols > 0 && n_groups > 0 && n_groups <= 64 && n_genes >= 0 && n_genes <= 65535);
+int mm_valid_cols(const double *d_ym, const double *d_yv, int64_t ld, int32_t num_boot, int32_t n_groups, const uint8_t *d_good,
+                  int64_t n_genes, int32_t *d_col_map, int32_t *d_n_valid, void *stream) {
+  MM_ARG(d_ym && d_yv && d_good && d_col_map && d_n_valid && n_groups > 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  MM_ARG(n_genes >= 0 && n_genes < 2147483647LL);
   if (n_genes == 0) return MM_OK;
-  size_t shm = (size_t)n_groups * n_groups * 8;
-  hipLaunchKernelGGL(k_residualize, dim3((unsigned)((n_cols + 255) / 256), (unsigned)n_genes), dim3(256), shm, (hipStream_t)stream, d_y,
-                     ld, n_cols, n_groups, d_gene_mask, d_M);
+  size_t shm = (size_t)n_groups * 4;
+  hipLaunchKernelGGL(k_valid_cols, dim3((unsigned)n_genes), dim3(256), shm, (hipStream_t)stream, d_ym, d_yv, ld, num_boot, n_groups,
+                     d_good, d_col_map, d_n_valid);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_residualize(const double *d_src, double *d_dst, int64_t ld, int32_t n_cols, int32_t n_groups, int64_t n_genes,
+                   const int32_t *d_gene_mask, const double *d_M, void *stream) {
+  MM_ARG(d_src && d_dst && d_src != d_dst && d_gene_mask && d_M && n_cols > 0 && n_groups > 0 && n_genes >= 0);
+  MM_ARG((size_t)n_groups * 8 <= 64 * 1024);
+  if (n_genes == 0) return MM_OK;
+  int32_t col_tiles = (n_cols + 255) / 256;
+  MM_ARG(n_genes * col_tiles < 2147483647LL);
+  size_t shm = (size_t)n_groups * 8;
+  hipLaunchKernelGGL(k_residualize, dim3((unsigned)(n_genes * col_tiles)), dim3(256), shm, (hipStream_t)stream, d_src, d_dst, ld, n_cols,
+                     n_groups, col_tiles, d_gene_mask, d_M);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
 int mm_cross_resampled(const double *d_yt, int64_t ld, int32_t num_boot, int32_t n_groups, const int32_t *d_test_gene,
                        const double *d_tt, const uint8_t *d_good, const double *d_Nc, const int16_t *d_rep, const int32_t *d_bcol,
-                       uint64_t seed, int64_t n_tests, double *d_coef, double *d_stats, int32_t *d_status, void *stream) {
-  MM_ARG(d_yt && d_test_gene && d_tt && d_good && d_Nc && d_coef && d_stats && d_status);
-  MM_ARG(n_tests >= 0 && n_groups > 0 && num_boot > 1 && ld >= (int64_t)num_boot + 1 && ((d_rep == nullptr) == (d_bcol == nullptr)));
+                       const int32_t *d_col_map, const int32_t *d_n_valid, uint64_t seed, int64_t n_tests, double *d_coef,
+                       double *d_stats, void *stream) {
+  MM_ARG(d_yt && d_test_gene && d_tt && d_good && d_Nc && d_coef && d_stats);
+  MM_ARG(n_tests >= 0 && n_tests < 2147483647LL && n_groups > 0 && n_groups <= 32767 && num_boot > 1 && ld >= (int64_t)num_boot + 1);
+  MM_ARG(((d_rep == nullptr) == (d_bcol == nullptr)) && ((d_col_map == nullptr) == (d_n_valid == nullptr)));
   if (n_tests == 0) return MM_OK;
   size_t shm = (size_t)n_groups * 20 + 8;
   hipLaunchKernelGGL(k_cross_resampled, dim3((unsigned)n_tests), dim3(K9_THREADS), shm, (hipStream_t)stream, d_yt, ld, num_boot, n_groups,
-                     d_test_gene, d_tt, d_good, d_Nc, d_rep, d_bcol, seed, d_coef, d_stats, d_status);
+                     d_test_gene, d_tt, d_good, d_Nc, d_rep, d_bcol, d_col_map, d_n_valid, seed, d_coef, d_stats);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

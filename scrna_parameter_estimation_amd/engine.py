@@ -559,28 +559,47 @@ class Bootstrap1D:
 
         return host(st_m)[:n_tests], host(st_v)[:n_tests], rows
 
-    def contract_resampled(self, test_gene, tt, good, which, gene_mask, M, Nc, rep=None, bcol=None, seed=0):
-        """resample_rep=True: residualise the response rows (copy), then the resampled weighted slopes + null statistics.
-        ``rep``/``bcol`` [n_genes][n_groups][B] (int16/int32) replay np.random.choice; None -> drawn on the device."""
-        torch = _torch()
-        s = _stream()
-        n_tests = len(test_gene)
-        src = self.yv if which else self.ym
-        yt = src.clone()
-        d_gm, d_M = dev(np.asarray(gene_mask, dtype=np.int32)), dev(np.asarray(M, dtype=np.float64))
-        _lib.call("mm_residualize", P(yt), self.ld, self.ld, self.ng, self.n_tested, P(d_gm), P(d_M), s)
-        coef = empty((max(1, n_tests), self.ld), torch.float64)
-        stats = empty((max(1, n_tests), 8), torch.float64)
-        status = zeros((1,), torch.int32)
-        d_tg, d_tt, d_good = dev(np.asarray(test_gene, dtype=np.int32)), dev(np.asarray(tt, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
-        d_nc = dev(np.asarray(Nc, dtype=np.float64))
-        d_rep = dev(np.asarray(rep, dtype=np.int16)) if rep is not None else None
-        d_bcol = dev(np.asarray(bcol, dtype=np.int32)) if bcol is not None else None
-        _lib.call("mm_cross_resampled", P(yt), self.ld, self.B, self.ng, P(d_tg), P(d_tt), P(d_good), P(d_nc), P(d_rep), P(d_bcol),
-                  int(seed) & ((1 << 64) - 1), n_tests, P(coef), P(stats), P(status), s)
-        if int(status.item()) & 1:
-            raise NotImplementedError("resample_rep=True with non-finite replicate columns (the reference would drop them)")
-        return coef, host(stats)[:n_tests]
+    def valid_cols(self, good):
+        """hypothesis_test.py:249-251 on the device: (col_map device tensor [n_tested][B+1], n_valid host [n_tested]) --
+        the replicate columns in which every good group is finite in both the mean and the variability rows."""
+        return _valid_cols(self.ym, self.yv, self.ld, self.B, self.ng, good, self.n_tested)
+
+    def contract_resampled(self, test_gene, tt, good, which, gene_mask, M, Nc, rep=None, bcol=None, seed=0, col_map=None, n_valid=None):
+        """resample_rep=True: residualise the response rows (into a scratch copy), then the resampled weighted slopes + null
+        statistics.  ``rep``/``bcol`` [n_genes][n_groups][B] (int16/int32) replay np.random.choice; None -> drawn on the
+        device.  ``col_map``/``n_valid`` (from ``valid_cols``): surviving replicate columns, None = all of them."""
+        return _contract_resampled(self.yv if which else self.ym, self.ld, self.B, self.ng, self.n_tested, test_gene, tt, good, gene_mask,
+                                   M, Nc, rep, bcol, seed, col_map, n_valid)
+
+
+def _valid_cols(ym, yv, ld, B, ng, good, n_genes):
+    torch = _torch()
+    col_map = empty((max(1, n_genes), B + 1), torch.int32)
+    n_valid = empty((max(1, n_genes),), torch.int32)
+    d_good = dev(np.asarray(good, dtype=np.uint8))
+    _lib.call("mm_valid_cols", P(ym), P(yv), ld, B, ng, P(d_good), n_genes, P(col_map), P(n_valid), _stream())
+    return col_map, host(n_valid)[:n_genes]
+
+
+def _contract_resampled(src, ld, B, ng, n_genes, test_gene, tt, good, gene_mask, M, Nc, rep, bcol, seed, col_map, n_valid):
+    torch = _torch()
+    s = _stream()
+    n_tests = len(test_gene)
+    if ng > 32767:
+        raise NotImplementedError("resample_rep=True with more than 32767 groups")
+    yt = torch.empty_like(src)
+    d_gm, d_M = dev(np.asarray(gene_mask, dtype=np.int32)), dev(np.asarray(M, dtype=np.float64))
+    _lib.call("mm_residualize", P(src), P(yt), ld, ld, ng, n_genes, P(d_gm), P(d_M), s)
+    coef = empty((max(1, n_tests), ld), torch.float64)
+    stats = empty((max(1, n_tests), 8), torch.float64)
+    d_tg, d_tt, d_good = dev(np.asarray(test_gene, dtype=np.int32)), dev(np.asarray(tt, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
+    d_nc = dev(np.asarray(Nc, dtype=np.float64))
+    d_rep = dev(np.asarray(rep, dtype=np.int16)) if rep is not None else None
+    d_bcol = dev(np.asarray(bcol, dtype=np.int32)) if bcol is not None else None
+    d_nv = dev(np.asarray(n_valid, dtype=np.int32)) if n_valid is not None else None
+    _lib.call("mm_cross_resampled", P(yt), ld, B, ng, P(d_tg), P(d_tt), P(d_good), P(d_nc), P(d_rep), P(d_bcol),
+              P(col_map if n_valid is not None else None), P(d_nv), int(seed) & ((1 << 64) - 1), n_tests, P(coef), P(stats), s)
+    return coef, host(stats)[:n_tests]
 
 
 # =================================================================================================
@@ -746,27 +765,15 @@ class Bootstrap2D:
         self.active = active
         self.pair_slot = pair_slot
 
-    def contract_resampled(self, test_pair, tt, good, pair_mask, M, Nc, rep=None, bcol=None, seed=0):
-        """resample_rep=True on the correlation rows (hypothesis_test.py:393-404): residualise (copy), then the resampled
-        weighted slopes + null statistics.  Same kernels and conventions as Bootstrap1D.contract_resampled."""
-        torch = _torch()
-        s = _stream()
-        n_tests = len(test_pair)
-        yt = self.yc.clone()
-        d_pm, d_M = dev(np.asarray(pair_mask, dtype=np.int32)), dev(np.asarray(M, dtype=np.float64))
-        _lib.call("mm_residualize", P(yt), self.ld, self.ld, self.ng, self.n_q // self.ng, P(d_pm), P(d_M), s)
-        coef = empty((max(1, n_tests), self.ld), torch.float64)
-        stats = empty((max(1, n_tests), 8), torch.float64)
-        status = zeros((1,), torch.int32)
-        d_tp, d_tt, d_good = dev(np.asarray(test_pair, dtype=np.int32)), dev(np.asarray(tt, dtype=np.float64)), dev(np.asarray(good, dtype=np.uint8))
-        d_nc = dev(np.asarray(Nc, dtype=np.float64))
-        d_rep = dev(np.asarray(rep, dtype=np.int16)) if rep is not None else None
-        d_bcol = dev(np.asarray(bcol, dtype=np.int32)) if bcol is not None else None
-        _lib.call("mm_cross_resampled", P(yt), self.ld, self.B, self.ng, P(d_tp), P(d_tt), P(d_good), P(d_nc), P(d_rep), P(d_bcol),
-                  int(seed) & ((1 << 64) - 1), n_tests, P(coef), P(stats), P(status), s)
-        if int(status.item()) & 1:
-            raise NotImplementedError("resample_rep=True with non-finite replicate columns (the reference would drop them)")
-        return coef, host(stats)[:n_tests]
+    def valid_cols(self, good):
+        """hypothesis_test.py:372-373 on the device (see Bootstrap1D.valid_cols)."""
+        return _valid_cols(self.yc, self.yc, self.ld, self.B, self.ng, good, self.n_q // self.ng)
+
+    def contract_resampled(self, test_pair, tt, good, pair_mask, M, Nc, rep=None, bcol=None, seed=0, col_map=None, n_valid=None):
+        """resample_rep=True on the correlation rows (hypothesis_test.py:393-404).  Same kernels and conventions as
+        Bootstrap1D.contract_resampled."""
+        return _contract_resampled(self.yc, self.ld, self.B, self.ng, self.n_q // self.ng, test_pair, tt, good, pair_mask, M, Nc, rep, bcol,
+                                   seed, col_map, n_valid)
 
     def contract(self, test_pair, W, good):
         """K9/K10 on the correlation rows: tests (sorted pair index, weight row)."""

@@ -384,14 +384,19 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             gmask = ((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng]
             return not (t[gmask] == 1).mean() == 1                                                   # hypothesis_test.py:262
 
+        nb_eff = {}      # genes whose replicate columns are not all finite: columns left after hypothesis_test.py:249-251, minus one
+
         def draw_assignments(gi):
             n = int(((~skip) & (bs.K >= 2) & ~known_bad)[gi * ng:(gi + 1) * ng].sum())
             if gene_uses_resampling(gi, n):
-                ra = np.random.choice(n, size=(n, num_boot))
+                nb = nb_eff.get(gi, num_boot)                                  # hypothesis_test.py:253
+                if nb < 1:
+                    return
+                ra = np.random.choice(n, size=(n, nb))                         # hypothesis_test.py:275-278
                 ra[:, 0] = np.arange(n)
-                ba = np.random.choice(num_boot, (n, num_boot)) + 1
+                ba = np.random.choice(nb, (n, nb)) + 1
                 ba[:, 0] = 0
-                rep_assign[gi, :n], bcol_assign[gi, :n] = ra, ba
+                rep_assign[gi, :n, :nb], bcol_assign[gi, :n, :nb] = ra, ba
 
         def draw_stream(first, stop_pair=None, pending=None):
             """Consume the global np.random stream exactly as the reference does from pair ``first`` on: per gene the two
@@ -420,37 +425,60 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
             bad_fill = (n_inv < 0).any(axis=1)
         else:
-            n_inv_all = np.zeros((n_pairs, 2), dtype=np.int32)
-            first, pending = 0, None
-            while first < n_pairs:
-                saved = np.random.get_state()
-                draw_stream(first, pending=pending)
-                after = np.random.get_state()
-                n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first, mean_only=mean_only)
-                n_inv_all[first:] = n_inv
-                event = (n_inv > 0).any(axis=1)
-                if resample_rep:
-                    event |= (n_inv < 0).any(axis=1) & ~known_bad[first:]      # a group without valid replicates shrinks num_rep
-                needs = np.flatnonzero((~skip[first:]) & event) + first
-                if len(needs) == 0:
-                    np.random.set_state(after)
-                    pending = None
+            def strict_pass():
+                """One sequential replay of the reference's global-stream consumption over all genes (speculate, then roll back to
+                the first pair whose _fill draws -- or, under resample_rep, shrinking num_rep -- shift the stream)."""
+                n_inv_all = np.zeros((n_pairs, 2), dtype=np.int32)
+                first, pending = 0, None
+                while first < n_pairs:
+                    saved = np.random.get_state()
+                    draw_stream(first, pending=pending)
+                    after = np.random.get_state()
+                    n_inv = bs.run(skip, r1, r0, fit, fill_mode=1, first_pair=first, mean_only=mean_only)
+                    n_inv_all[first:] = n_inv
+                    event = (n_inv > 0).any(axis=1)
+                    if resample_rep:
+                        event |= (n_inv < 0).any(axis=1) & ~known_bad[first:]      # a group without valid replicates shrinks num_rep
+                    needs = np.flatnonzero((~skip[first:]) & event) + first
+                    if len(needs) == 0:
+                        np.random.set_state(after)
+                        pending = None
+                        break
+                    p = int(needs[0])
+                    np.random.set_state(saved)
+                    draw_stream(first, stop_pair=p, pending=pending)                # everything the reference drew up to pair p's hash
+                    for t, col in ((bs.ym, 0), (bs.yv, 1)):
+                        if n_inv_all[p, col] > 0:
+                            row = engine.host(t[p, 1:])
+                            t[p, 1:] = engine.dev(_host_fill(row))
+                            n_inv_all[p, col] = 0
+                    if (n_inv_all[p] < 0).any():
+                        known_bad[p] = True
+                    pending = p // ng if (resample_rep and p % ng == ng - 1) else None
+                    first = p + 1
+                if pending is not None:
+                    draw_assignments(pending)
+                return (n_inv_all < 0).any(axis=1)
+
+            stream0 = np.random.get_state()
+            for _attempt in range(3):
+                bad_fill = strict_pass()
+                if not resample_rep:
                     break
-                p = int(needs[0])
-                np.random.set_state(saved)
-                draw_stream(first, stop_pair=p, pending=pending)                # everything the reference drew up to pair p's hash
-                for t, col in ((bs.ym, 0), (bs.yv, 1)):
-                    if n_inv_all[p, col] > 0:
-                        row = engine.host(t[p, 1:])
-                        t[p, 1:] = engine.dev(_host_fill(row))
-                        n_inv_all[p, col] = 0
-                if (n_inv_all[p] < 0).any():
-                    known_bad[p] = True
-                pending = p // ng if (resample_rep and p % ng == ng - 1) else None
-                first = p + 1
-            if pending is not None:
-                draw_assignments(pending)
-            bad_fill = (n_inv_all < 0).any(axis=1)
+                # The reference draws a gene's assignments for the replicate columns that SURVIVE hypothesis_test.py:249-251,
+                # which is known only after its bootstrap: when a resampled gene lost columns, replay once more with that count.
+                good_now = ((~skip) & (bs.K >= 2) & ~bad_fill).reshape(G, ng)
+                _, nv = bs.valid_cols(good_now)
+                redo = False
+                for gi in np.flatnonzero(nv != num_boot + 1):
+                    gi = int(gi)
+                    if gene_uses_resampling(gi, int(good_now[gi].sum())) and nb_eff.get(gi, num_boot) != int(nv[gi]) - 1:
+                        nb_eff[gi] = int(nv[gi]) - 1
+                        redo = True
+                if not redo:
+                    break
+                np.random.set_state(stream0)
+                known_bad[:] = False
 
         active_all = (~skip) & (bs.K >= 2)                       # bootstrap.py:97-98: a single bin gives NaN replicates
         good = (active_all & ~bad_fill).reshape(G, ng)           # hypothesis_test.py:193-200
@@ -501,11 +529,16 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 ti += nt
             tt_mat = np.concatenate(tt_rows, axis=0)
             Mstack = np.stack(Ms)
+        col_map = n_valid = None
+        if use_rr and rr_test.any():
+            col_map, n_valid = bs.valid_cols(good)                  # hypothesis_test.py:249-251
+            if (n_valid[good.any(axis=1)] == num_boot + 1).all():
+                col_map = n_valid = None                            # nothing dropped (the usual case): identity map
         for which, tag in ((0, 'mean'), (1, 'var')):
             coef, stt = bs.contract(test_gene, Wmat, good, which)                                         # K9+K10
             if use_rr and rr_test.any():
                 coef_r, stt_r = bs.contract_resampled(test_gene, tt_mat, good, which, gene_mask, Mstack, Nc_list,
-                                                      rep_assign, bcol_assign, seed=fill_seed + 17)
+                                                      rep_assign, bcol_assign, seed=fill_seed + 17, col_map=col_map, n_valid=n_valid)
                 stt = np.where(rr_test[:, None], stt_r, stt)
                 rr_idx = engine.dev(np.flatnonzero(rr_test))
                 coef[rr_idx] = coef_r[rr_idx]
@@ -688,11 +721,13 @@ def get_corr_matrix(adata, group):
     mu = st.S[0][gi, st.gene_idx] / n
     cov = P - np.outer(mu, mu)
     var = m['1d_moments'][group][1]
-    var[var <= 0] = np.nan                                                                     # in place, like estimator.py:261
-    vp = np.sqrt(np.outer(var, var))
-    corr = np.full(cov.shape, 5.0)
-    ok = np.isfinite(vp)
-    corr[ok] = cov[ok] / vp[ok]
+    # estimator.py:259-263: the reference NaNs only fancy-index copies; var_prod comes from the untouched variances
+    # (negative x negative -> finite product, negative x positive -> NaN, zero -> division by zero -> NaN below)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        vp = np.sqrt(np.outer(var, var))
+        corr = np.full(cov.shape, 5.0)
+        ok = np.isfinite(vp)
+        corr[ok] = cov[ok] / vp[ok]
     inside = (corr < 1.05) & (corr > -1.05)
     corr[inside] = np.clip(corr[inside], a_min=-1, a_max=1)
     corr[(corr > 1) | (corr < -1)] = np.nan
@@ -700,11 +735,13 @@ def get_corr_matrix(adata, group):
 
 
 def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=True, num_boot=10000, verbose=3, num_cpus=1,
-                  max_rows=None, fill_seed=0, **kwargs):
+                  max_rows=None, fill_seed=0, strict=False, **kwargs):
     """Bootstrap hypothesis test of correlation differences (reference: memento/main.py:418-520,
     hypothesis_test._ht_2d :303-364).  Same replay semantics as ht_1d_moments.  ``resample_rep=True``
-    (hypothesis_test.py:393-404): the group / replicate-column assignments are drawn on the device (seeded by
-    ``fill_seed``), i.e. statistically equivalent to the reference's np.random.choice draws, not draw-identical."""
+    (hypothesis_test.py:393-404): with ``strict=True`` the reference's two np.random.choice draws per pair are replayed from
+    the global stream in pair order (exact agreement with the reference at num_cpus=1); otherwise the group /
+    replicate-column assignments are drawn on the device (seeded by ``fill_seed``): statistically equivalent, not
+    draw-identical.  Without resample_rep the 2D path consumes the global stream exactly like the reference either way."""
     if 'resampling' not in kwargs:
         raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
     if treatment_for_gene is not None:
@@ -745,9 +782,11 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     with np.errstate(invalid="ignore"):
         skip = np.isnan(true_corr) | (np.abs(true_corr) == 1)                                  # hypothesis_test.py:325
     live = ~skip.reshape(-1)
-    u = np.random.random(3 * int(live.sum()))            # r = random(2) then r0 = random() per live (pair, group), in order
     r1a, r1b, r0 = (np.zeros(P_ * ng) for _ in range(3))
-    r1a[live], r1b[live], r0[live] = u[0::3], u[1::3], u[2::3]
+    replay_rr = resample_rep and strict                   # the choice draws interleave with the hash uniforms, pair by pair
+    if not replay_rr:
+        u = np.random.random(3 * int(live.sum()))        # r = random(2) then r0 = random() per live (pair, group), in order
+        r1a[live], r1b[live], r0[live] = u[0::3], u[1::3], u[2::3]
     corr_coef, corr_se, corr_asl = (np.full(n_conv, np.nan) for _ in range(3))
     bs = None
     # pairs are independent: process them in chunks so the replicate rows ([pair x group][B+1] fp64) stay bounded
@@ -760,6 +799,28 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         bs = engine.Bootstrap2D(st.cols, c1[lo:hi], c2[lo:hi], st.maxx, st.sf_bin, st.sf_table, gq, num_boot)
         so = bs.order                                     # device pair order (sorted by left column)
         sl = slice(lo * ng, hi * ng)
+        rep_assign = bcol_assign = None
+        if replay_rr:
+            # global-stream order of the reference for one pair (_ht_2d :319-343, _regress_2d :395-398): three uniforms per
+            # live group, then -- unless the treatment of the good groups is all ones -- the two np.random.choice draws
+            inv = np.empty(n_ch, dtype=np.int64)
+            inv[so] = np.arange(n_ch)
+            K_orig = bs.K.reshape(n_ch, ng)[inv]                                  # bins per (pair, group), original pair order
+            rep_assign = np.zeros((n_ch, ng, num_boot), dtype=np.int16)          # device pair order
+            bcol_assign = np.zeros((n_ch, ng, num_boot), dtype=np.int32)
+            for pi in range(n_ch):
+                lv = ~skip[lo + pi]
+                idx = (lo + pi) * ng + np.flatnonzero(lv)
+                uu = np.random.random(3 * len(idx))
+                r1a[idx], r1b[idx], r0[idx] = uu[0::3], uu[1::3], uu[2::3]
+                gd = lv & (K_orig[pi] >= 1)
+                n = int(gd.sum())
+                if n and not (trt[gd] == 1).mean() == 1:
+                    ra = np.random.choice(n, size=(n, num_boot))
+                    ra[:, 0] = np.arange(n)
+                    ba = np.random.choice(num_boot, (n, num_boot)) + 1
+                    ba[:, 0] = 0
+                    rep_assign[inv[pi], :n], bcol_assign[inv[pi], :n] = ra, ba
 
         def to_dev_order(a):
             return a[sl].reshape(n_ch, ng)[so].reshape(-1)
@@ -790,8 +851,14 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 tt_rows.append(ttg)
                 rr_test[k] = good[k].any() and not allones
             if rr_test.any():
+                col_map, n_valid = bs.valid_cols(good)                            # hypothesis_test.py:372-373
+                if (n_valid[good.any(axis=1)] == num_boot + 1).all():
+                    col_map = n_valid = None
+                elif replay_rr:
+                    raise NotImplementedError("strict replay of resample_rep with non-finite correlation replicates")
                 coef_r, stt_r = bs.contract_resampled(np.arange(n_ch), np.concatenate(tt_rows, axis=0), good, pair_mask, np.stack(Ms),
-                                                      Nc_list, seed=fill_seed + 17 + lo)
+                                                      Nc_list, rep=rep_assign, bcol=bcol_assign, seed=fill_seed + 17 + lo,
+                                                      col_map=col_map, n_valid=n_valid)
                 stt = np.where(rr_test[:, None], stt_r, stt)
                 rr_idx = engine.dev(np.flatnonzero(rr_test))
                 coef[rr_idx] = coef_r[rr_idx]

@@ -58,6 +58,26 @@ def regress_asl():
     return load_golden("regress_asl")
 
 
+@pytest.fixture(scope="session")
+def corrmat_negvar():
+    return load_golden("corrmat_negvar")
+
+
+@pytest.fixture(scope="session")
+def api_rr16():
+    return load_golden("api_rr16")
+
+
+@pytest.fixture(scope="session")
+def api_c1():
+    return load_golden("api_c1")
+
+
+@pytest.fixture(scope="session")
+def guide_loop():
+    return load_golden("guide_loop")
+
+
 def golden_inputs(g):
     """Rebuild (X csr float64, group_id, n_groups, q) from a golden api_* fixture."""
     import scipy.sparse as sp
@@ -67,3 +87,15 @@ def golden_inputs(g):
     groups = list(g["groups"])
     gid = np.array([groups.index(l) for l in labels], dtype=np.int32)
     return X, gid, len(groups), g["in_q"]
+
+
+def c1_inputs(g):
+    """(X csr float64, group_id, n_groups, q) of the api_c1 fixture (BASELINE configs[0] shape; compact integer storage)."""
+    import scipy.sparse as sp
+
+    X = sp.csr_matrix((g["in_data"].astype(np.float64), g["in_indices"].astype(np.int32), g["in_indptr"].astype(np.int32)),
+                      shape=tuple(g["in_shape"]))
+    labels = np.array([f"sg^{c}" for c in g["in_cond"]])
+    groups = list(g["groups"])
+    gid = np.array([groups.index(l) for l in labels], dtype=np.int32)
+    return X, gid, len(groups), float(g["in_q"])

@@ -340,7 +340,162 @@ def opts_case(name):
     print(name, "a genes", len(out["a_gene_list"]), "b vars", int(out["b_n_vars"]), "c genes", len(out["c_var_names"]))
 
 
+def corrmat_case(name, seed):
+    """get_corr_matrix on a group holding genes whose variance estimate is negative or exactly zero
+    (estimator.py:259-268: NaN only through copies, var_prod from the raw variances).  Low-count, nearly Poisson genes give
+    negative estimates by noise; one gene is made constant-free (a single count-1 cell pattern) to land near zero."""
+    import scipy.sparse as sp
+    from scrna_parameter_estimation_amd.anndata_lite import AnnDataLite
+
+    rng = np.random.default_rng(seed)
+    n_cells, n_genes = 1600, 48
+    depth = rng.lognormal(0.0, 0.25, size=n_cells)
+    mu = rng.uniform(0.09, 0.6, size=n_genes)
+    x = rng.poisson(depth[:, None] * mu[None, :]).astype(np.float64)         # no extra dispersion: var estimates straddle 0
+    X = sp.csr_matrix(x)
+    grp = rng.integers(0, 4, size=n_cells)
+    obs = pd.DataFrame({"cond": (grp // 2).astype(np.int64), "rep": (grp % 2).astype(np.int64), "q": np.full(n_cells, 0.07)},
+                       index=[f"c{i}" for i in range(n_cells)])
+    adata = AnnDataLite(X, obs, pd.DataFrame(index=[f"g{i}" for i in range(n_genes)]))
+    inp = dict(indptr=X.indptr.copy(), indices=X.indices.copy(), data=X.data.copy(), shape=np.array(X.shape),
+               cond=obs["cond"].values.copy(), rep=obs["rep"].values.copy(), q=obs["q"].values.copy(),
+               gene_names=np.array(adata.var.index.tolist()))
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    m = adata.uns["memento"]
+    groups = list(m["groups"])
+    out = {"groups": np.array(groups), "gene_list": np.array(m["gene_list"]), "size_factor": adata.obs["memento_size_factor"].values.copy(),
+           "overall_gene_filter": m["overall_gene_filter"].copy(),
+           "var": np.stack([m["1d_moments"][g][1] for g in groups]), "group_q": np.array([m["group_q"][g] for g in groups])}
+    nneg = [(out["var"][i] <= 0).sum() for i in range(len(groups))]
+    for i, g in enumerate(groups):
+        before = m["1d_moments"][g][1].copy()
+        out[f"corr_matrix_{i}"] = memento.get_corr_matrix(adata, g)
+        assert np.array_equal(before, m["1d_moments"][g][1], equal_nan=True)      # the reference leaves uns untouched
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{("in_" + k): v for k, v in inp.items()}, **out)
+    print(name, "genes kept", len(out["gene_list"]), "var<=0 per group", nneg)
+
+
+def rr16_case(name, seed, num_boot, two_d_pairs):
+    """resample_rep=True through the API with 2 x 8 groups: a resampled column is degenerate (every drawn group has the same
+    treatment) with probability 2 * 2^-16 = 3e-5, i.e. none here -- so SEs and p-values of the real reference are
+    free of its 0/0 round-off noise and can be pinned tightly.  1D (hypothesis_test.py:273-286) and 2D (:393-404)."""
+    adata = synth_adata(6400, 160, 0.15, 2, 8, seed, dtype=np.float64)
+    inp = dict(indptr=adata.X.indptr.copy(), indices=adata.X.indices.copy(), data=adata.X.data.copy(), shape=np.array(adata.X.shape),
+               cond=adata.obs["cond"].values.copy(), rep=adata.obs["rep"].values.copy(), q=adata.obs["q"].values.copy(),
+               gene_names=np.array(adata.var.index.tolist()))
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    m = adata.uns["memento"]
+    groups = list(m["groups"])
+    out = {"estimator_type": np.array("hyper_relative"), "groups": np.array(groups), "gene_list": np.array(m["gene_list"]),
+           "overall_gene_filter": m["overall_gene_filter"].copy(), "approx_sf": m["all_approx_size_factor"].copy(),
+           "group_q": np.array([m["group_q"][g] for g in groups]),
+           "mean": np.stack([m["1d_moments"][g][0] for g in groups]), "res_var": np.stack([m["1d_moments"][g][2] for g in groups]),
+           "mv_regressor": np.asarray(m["mv_regressor"][groups[0]]).copy(), "num_boot": np.int64(num_boot)}
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf)), "rep": gdf["rep"].astype(float).values}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == 1).astype(float)}, index=gdf.index)
+    out["covariate"], out["treatment"] = cov.values.copy(), trt.values.copy()
+    for tag, approx, sd in (("exact", False, 61), ("approx", True, 62)):
+        np.random.seed(sd)
+        memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=num_boot, num_cpus=1, verbose=0,
+                              resampling="bootstrap", approx=approx, resample_rep=True)
+        for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+            out[f"htrr_{tag}_{k}"] = np.asarray(m["1d_ht"][k]).copy()
+        out[f"seed_{tag}"] = np.int64(sd)
+    G = adata.shape[1]
+    rng = np.random.default_rng(seed + 7)
+    i1 = rng.integers(0, G, size=two_d_pairs)
+    i2 = (i1 + 1 + rng.integers(0, G - 1, size=two_d_pairs)) % G
+    names = adata.var.index.values
+    memento.compute_2d_moments(adata, list(zip(names[i1].tolist(), names[i2].tolist())))
+    out["pair_idx1"], out["pair_idx2"] = i1, i2
+    out["true_corr"] = np.stack([m["2d_moments"][g]["corr"] for g in groups])
+    out["size_factor"] = adata.obs["memento_size_factor"].values.copy()
+    np.random.seed(63)
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=num_boot, num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=False, resample_rep=True)
+    for k in ["corr_coef", "corr_se", "corr_asl"]:
+        out["ht2rr_" + k] = np.asarray(m["2d_ht"][k]).copy()
+    out["seed_2d"] = np.int64(63)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{("in_" + k): v for k, v in inp.items()}, **out)
+    print(name, "genes kept", len(out["gene_list"]), "groups", len(groups), "finite 2d", np.isfinite(out["ht2rr_corr_asl"]).sum())
+
+
+def c1_case(name):
+    """BASELINE.json configs[0]: PBMC-3k shape (2.7k cells x 1.8k genes), 2 groups, 100 bootstraps, full 1D path of the real
+    reference at num_cpus=1 (synthetic PBMC-3k-shaped counts: the dataset itself is not available offline)."""
+    adata = synth_adata(2700, 1800, 0.10, 2, 1, 101, dtype=np.float64)
+    X = adata.X
+    assert X.data.max() < 65536 and X.shape[1] < 65536
+    inp = dict(indptr=X.indptr.astype(np.int32), indices=X.indices.astype(np.uint16), data=X.data.astype(np.uint16), shape=np.array(X.shape),
+               cond=adata.obs["cond"].values.astype(np.int8), q=np.float64(adata.obs["q"].values[0]))
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    m = adata.uns["memento"]
+    groups = list(m["groups"])
+    out = {"groups": np.array(groups), "size_factor": adata.obs["memento_size_factor"].values.copy(),
+           "overall_gene_filter": m["overall_gene_filter"].copy(),
+           "mean": np.stack([m["1d_moments"][g][0] for g in groups]), "var": np.stack([m["1d_moments"][g][1] for g in groups]),
+           "res_var": np.stack([m["1d_moments"][g][2] for g in groups])}
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == 1).astype(float)}, index=gdf.index)
+    out["covariate"], out["treatment"] = cov.values.copy(), trt.values.copy()
+    np.random.seed(71)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=100, num_cpus=1, verbose=0, resampling="bootstrap", approx=False)
+    for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+        out["ht_" + k] = np.asarray(m["1d_ht"][k]).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{("in_" + k): v for k, v in inp.items()}, **out)
+    print(name, "genes kept", int(out["overall_gene_filter"].sum()), "finite p", np.isfinite(out["ht_mean_asl"]).sum())
+
+
+def guide_loop_case(name):
+    """The reference's Perturb-seq pattern on the current API (analysis/sciplex/sciplex_dv.py:18-40 style): for every guide,
+    subset to control + guide cells, create_groups, compute_1d_moments, ht_1d_moments.  Fixture for measuring how far the
+    batched ht_1d_vs_control (one pooled mean-variance fit, one bootstrap of the control) is from this loop."""
+    from scrna_parameter_estimation_amd.anndata_lite import AnnDataLite
+    import copy
+
+    n_guides = 5
+    adata = synth_adata(6000, 150, 0.15, 1, 1, 131, dtype=np.float64)
+    rng = np.random.default_rng(132)
+    guide = rng.integers(0, n_guides + 1, size=adata.shape[0])
+    guide[rng.random(adata.shape[0]) < 0.15] = 0                    # extra control cells (guide 0 = control)
+    adata.obs["guide"] = guide
+    inp = dict(indptr=adata.X.indptr.copy(), indices=adata.X.indices.copy(), data=adata.X.data.copy(), shape=np.array(adata.X.shape),
+               guide=guide.astype(np.int64), q=adata.obs["q"].values.copy(), gene_names=np.array(adata.var.index.tolist()))
+    memento.setup_memento(adata, q_column="q")
+    out = {"size_factor": adata.obs["memento_size_factor"].values.copy(), "n_guides": np.int64(n_guides)}
+    for gid in range(1, n_guides + 1):
+        rows = np.flatnonzero((guide == 0) | (guide == gid))
+        sub = AnnDataLite(adata.X[rows].tocsr(), adata.obs.iloc[rows].copy(), adata.var.copy(), copy.deepcopy(adata.uns))
+        sub.obs["is_guide"] = (sub.obs["guide"].values == gid).astype(int)
+        memento.create_groups(sub, label_columns=["is_guide"])
+        memento.compute_1d_moments(sub, min_perc_group=0.9)
+        gdf = memento.get_groups(sub)
+        cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+        trt = pd.DataFrame({"is_guide": gdf["is_guide"].astype(float).values}, index=gdf.index)
+        np.random.seed(140 + gid)
+        memento.ht_1d_moments(sub, covariate=cov, treatment=trt, num_boot=400, num_cpus=1, verbose=0, resampling="bootstrap", approx=True)
+        ht = sub.uns["memento"]["1d_ht"]
+        out[f"g{gid}_genes"] = np.array(sub.var.index.tolist())
+        for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+            out[f"g{gid}_{k}"] = np.asarray(ht[k]).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{("in_" + k): v for k, v in inp.items()}, **out)
+    print(name, [len(out[f"g{g}_genes"]) for g in range(1, n_guides + 1)])
+
+
 if __name__ == "__main__":
+    only = {"corrmat": lambda: corrmat_case("corrmat_negvar", seed=7), "rr16": lambda: rr16_case("api_rr16", seed=51, num_boot=300, two_d_pairs=10),
+            "c1": lambda: c1_case("api_c1"), "guides": lambda: guide_loop_case("guide_loop")}
+    if len(sys.argv) == 2 and sys.argv[1] in only:      # the round-2 fixtures (each reproducible on its own)
+        only[sys.argv[1]]()
+        sys.exit(0)
     if sys.argv[1:] == ["rr2d"]:
         regress2d_rr_case("regress2d_rr", seed=13)
         sys.exit(0)
@@ -361,3 +516,5 @@ if __name__ == "__main__":
     perm_case("api_perm", num_boot=300, ht_seed=21)
     opts_case("api_opts")
     regress2d_rr_case("regress2d_rr", seed=13)
+    for fn in only.values():
+        fn()

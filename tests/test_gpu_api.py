@@ -283,12 +283,14 @@ def test_ht_1d_fast_fill_statistically_equivalent(api_small):
     np.testing.assert_allclose(ht["mean_se"], whole["mean_se"], rtol=0.2, equal_nan=True)
 
 
-def test_ht_1d_resample_rep(api_small):
-    """resample_rep=True (hierarchical resampling of the replicate groups, hypothesis_test.py:273-286), strict replay
-    of the np.random.choice draws.  Columns whose drawn groups all share one treatment are 0/0: the reference reports
-    NaN or O(1) round-off noise for them depending on rounding; the kernel always reports NaN.  So: observed
-    coefficients match the real reference exactly, everything matches the oracle run with ``drop_degenerate`` (same
-    stream), and the reference's SEs -- which include that noise -- agree within a few percent."""
+def test_ht_1d_resample_rep_4_groups_degenerate_columns_are_a_deliberate_deviation(api_small):
+    """resample_rep=True with only 2 x 2 groups: 12.5 % of the resampled columns draw groups of ONE treatment value, where
+    the slope is 0/0.  The reference reports NaN or O(1) round-off noise for them (a ratio of two rounding residues, one
+    of them out of LAPACK's least-squares residuals -- not reproducible bit for bit); the kernel always reports NaN.
+    DELIBERATE DEVIATION: observed coefficients match the real reference exactly, everything matches
+    the oracle run with its non-reference ``drop_degenerate`` switch (same stream), and the reference's SEs -- which include
+    that noise -- agree within a few percent.  The noise-free case (16 groups) is pinned tightly in
+    test_ht_1d_resample_rep_16_groups_matches_reference."""
     from conftest import golden_inputs
     from oracle import memento_oracle as orc
 
@@ -469,3 +471,207 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmemento_hip.so")
     with pytest.raises(_lib.HipLibraryMissing):
         _lib.load()
+
+
+def test_corr_matrix_with_nonpositive_variances_matches_reference(corrmat_negvar):
+    """get_corr_matrix on groups holding genes with variance estimates <= 0, against the real reference
+    (estimator.py:259-268): same NaN mask, same finite values (1e-8), and no write into uns['memento']['1d_moments']."""
+    g = corrmat_negvar
+    memento, adata = _run_to_moments(g)
+    m = adata.uns["memento"]
+    assert m["gene_list"] == list(g["gene_list"])
+    for k, grp in enumerate(m["groups"]):
+        before = m["1d_moments"][grp][1].copy()
+        assert (before <= 0).any()
+        cm = memento.get_corr_matrix(adata, grp)
+        np.testing.assert_array_equal(before, m["1d_moments"][grp][1])
+        want = g[f"corr_matrix_{k}"]
+        np.testing.assert_array_equal(np.isnan(cm), np.isnan(want))
+        np.testing.assert_allclose(cm, want, rtol=1e-8, atol=1e-12, equal_nan=True)
+
+
+def _rr16_design(memento, adata, g):
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame(g["covariate"], index=gdf.index, columns=["intercept", "rep"])
+    trt = pd.DataFrame(g["treatment"], index=gdf.index, columns=["cond"])
+    return cov, trt
+
+
+@pytest.mark.parametrize("tag,approx", [("exact", False), ("approx", True)])
+def test_ht_1d_resample_rep_16_groups_matches_reference(api_rr16, tag, approx):
+    """resample_rep=True, 2 x 8 groups, intercept + numeric covariate: no resampled column is degenerate, so the strict
+    replay must reproduce the REAL reference: coefficients and standard errors to 1e-8, p-values to 1e-5."""
+    g = api_rr16
+    memento, adata = _run_to_moments(g)
+    assert list(adata.var.index) == list(g["gene_list"])
+    cov, trt = _rr16_design(memento, adata, g)
+    np.random.seed(int(g[f"seed_{tag}"]))
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=approx, resample_rep=True, strict=True)
+    ht = adata.uns["memento"]["1d_ht"]
+    for k in ["mean_coef", "mean_se", "var_coef", "var_se"]:
+        np.testing.assert_allclose(ht[k], g[f"htrr_{tag}_{k}"], rtol=1e-8, atol=1e-12, err_msg=k)
+    for k in ["mean_asl", "var_asl"]:
+        np.testing.assert_allclose(ht[k], g[f"htrr_{tag}_{k}"], rtol=1e-5, atol=1e-12, err_msg=k)
+
+
+def test_ht_2d_resample_rep_16_groups_matches_reference(api_rr16):
+    """ht_2d_moments(resample_rep=True, strict=True): the two np.random.choice draws of _regress_2d
+    (hypothesis_test.py:395-398) are replayed from the global stream in pair order -- real-reference fixture, 1e-8 / 1e-5."""
+    g = api_rr16
+    memento, adata = _run_to_moments(g)
+    names = np.asarray(adata.var.index)
+    pairs = list(zip(names[g["pair_idx1"]].tolist(), names[g["pair_idx2"]].tolist()))
+    memento.compute_2d_moments(adata, pairs)
+    m = adata.uns["memento"]
+    for i, k in enumerate(m["groups"]):
+        np.testing.assert_allclose(m["2d_moments"][k]["corr"], g["true_corr"][i], rtol=1e-8, equal_nan=True)
+    cov, trt = _rr16_design(memento, adata, g)
+    for max_rows in (None, 64):                  # whole pair list at once / 4 pairs per chunk: same stream order
+        np.random.seed(int(g["seed_2d"]))
+        memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0,
+                              resampling="bootstrap", approx=False, resample_rep=True, strict=True, max_rows=max_rows)
+        ht = m["2d_ht"]
+        np.testing.assert_allclose(ht["corr_coef"], g["ht2rr_corr_coef"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(ht["corr_se"], g["ht2rr_corr_se"], rtol=1e-8)
+        np.testing.assert_allclose(ht["corr_asl"], g["ht2rr_corr_asl"], rtol=1e-5)
+
+
+def test_ht_1d_resample_rep_one_group_per_donor():
+    """The reference's real use of resample_rep (analysis/lupus/run_memento.py:31-52): ONE GROUP PER DONOR (120 donors here,
+    far beyond the 64 groups round 1 stopped at), genotype-like numeric treatments chosen per gene (treatment_for_gene),
+    donor covariates -- strict replay against the oracle on the same stream."""
+    from oracle import memento_oracle as orc
+    from scrna_parameter_estimation_amd import AnnDataLite, memento
+    from scrna_parameter_estimation_amd.synth import synth_counts
+
+    n_donors, per, G, B = 120, 70, 40, 150
+    rng = np.random.default_rng(5)
+    X = synth_counts(n_donors * per, G, 0.25, seed=77, dtype=np.float32)
+    donor = rng.permutation(np.repeat(np.arange(n_donors), per))
+    obs = pd.DataFrame({"ind": [f"d{d:03d}" for d in donor], "q": np.full(len(donor), 0.1)}, index=[f"c{i}" for i in range(len(donor))])
+    adata = AnnDataLite(X, obs, pd.DataFrame(index=[f"g{i}" for i in range(G)]))
+    Xref = X.astype(np.float64).copy()
+    memento.setup_memento(adata, q_column="q", filter_mean_thresh=0.01)
+    memento.create_groups(adata, label_columns=["ind"])
+    memento.compute_1d_moments(adata, min_perc_group=0.9)
+    m = adata.uns["memento"]
+    groups = m["groups"]
+    ng = len(groups)
+    assert ng == n_donors
+    names = list(adata.var.index)
+    assert len(names) >= 5
+    geno = pd.DataFrame(rng.integers(0, 3, size=(ng, 3)).astype(float), index=groups, columns=["snp0", "snp1", "snp2"])
+    covd = pd.DataFrame({"intercept": np.ones(ng), "age": rng.normal(size=ng), "sex": rng.integers(0, 2, size=ng).astype(float)}, index=groups)
+    tfg = {n: (["snp0", "snp2"] if i % 2 else ["snp1"]) for i, n in enumerate(names)}
+    np.random.seed(9)
+    memento.ht_1d_moments(adata, covariate=covd, treatment=geno, treatment_for_gene=tfg, num_boot=B, num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=True, resample_rep=True, strict=True)
+    ht = {k: v.copy() for k, v in m["1d_ht"].items() if k.endswith(("coef", "se", "asl"))}
+    # oracle: same inputs, same global stream, gene by gene with the gene's own treatment columns
+    gid = m["_hip"].group_id
+    sf = adata.obs["memento_size_factor"].values
+    gq = np.array([m["group_q"][k] for k in groups])
+    keep = np.isin([f"g{i}" for i in range(G)], names)
+    mom = dict(mean=np.stack([m["1d_moments"][k][0] for k in groups]), res_var=np.stack([m["1d_moments"][k][2] for k in groups]),
+               mv_fit=m["mv_regressor"][groups[0]])
+    Xk = sp.csc_matrix(Xref[:, keep])
+    sel = [np.flatnonzero(gid == j) for j in range(ng)]
+    Nc = np.array([len(s_) for s_ in sel], dtype=float)
+    asf = [m["all_approx_size_factor"][s_] for s_ in sel]
+    np.random.seed(9)
+    want = [[] for _ in range(6)]
+    for gi, n in enumerate(names):
+        col = np.asarray(Xk[:, gi].todense()).ravel()
+        res = orc.ht_1d_gene(mom["mean"][:, gi], mom["res_var"][:, gi], [col[s_] for s_ in sel], asf, covd.values, geno[tfg[n]].values,
+                             Nc, B, mom["mv_fit"], gq, resampling="bootstrap", approx=True, resample_rep=True)
+        for o, r in zip(want, res):
+            o.append(np.atleast_1d(r) * np.ones(len(tfg[n])))
+    for k, w in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], want):
+        w = np.concatenate(w)
+        assert np.isfinite(w).all()
+        np.testing.assert_allclose(ht[k], w, rtol=1e-5 if k.endswith("asl") else 1e-8, atol=1e-12, err_msg=k)
+    # device-drawn assignments (the default, strict=False): same observed coefficients, SEs within Monte-Carlo error
+    np.random.seed(9)
+    memento.ht_1d_moments(adata, covariate=covd, treatment=geno, treatment_for_gene=tfg, num_boot=B, num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=True, resample_rep=True)
+    np.testing.assert_allclose(m["1d_ht"]["mean_coef"], ht["mean_coef"], rtol=1e-8)
+    assert np.median(np.abs(m["1d_ht"]["mean_se"] / ht["mean_se"] - 1)) < 0.2
+
+
+def test_resample_rep_drops_non_finite_replicate_columns():
+    """hypothesis_test.py:249-254: replicate columns with a non-finite entry (in the mean OR the variability rows of any group)
+    are dropped BEFORE the hierarchical resampling, which then draws among the survivors.  mm_valid_cols + mm_residualize +
+    mm_cross_resampled fed with the reference's np.random.choice draws against the oracle's _regress_1d restatement."""
+    from oracle import memento_oracle as orc
+    from scrna_parameter_estimation_amd import engine
+    from scrna_parameter_estimation_amd.memento import design
+
+    rng = np.random.default_rng(3)
+    ng, B = 10, 120
+    cov = np.column_stack([np.ones(ng), rng.normal(size=ng)])
+    trt = (np.arange(ng) % 2).astype(float).reshape(-1, 1)
+    Nc = rng.integers(200, 900, size=ng).astype(float)
+    bm = 0.1 * rng.normal(size=(ng, B + 1)) + 0.3 * trt
+    bv = 0.2 * rng.normal(size=(ng, B + 1))
+    bm[3, 17] = np.nan
+    bv[0, 40] = np.inf
+    bv[7, 41] = np.nan
+    bm[2, B] = -np.inf
+    np.random.seed(123)
+    want = orc.regress_1d(cov, trt, bm, bv, Nc, resampling="bootstrap", approx=True, resample_rep=True)
+    nb = B - 4
+    np.random.seed(123)
+    ra = np.random.choice(ng, size=(ng, nb)); ra[:, 0] = np.arange(ng)
+    ba = np.random.choice(nb, (ng, nb)) + 1; ba[:, 0] = 0
+    rep = np.zeros((1, ng, B), dtype=np.int16); rep[0, :, :nb] = ra
+    bcol = np.zeros((1, ng, B), dtype=np.int32); bcol[0, :, :nb] = ba
+    bs = object.__new__(engine.Bootstrap1D)
+    bs.ym, bs.yv, bs.ld, bs.B, bs.ng, bs.n_tested = engine.dev(bm), engine.dev(bv), B + 1, B, ng, 1
+    good = np.ones((1, ng), dtype=bool)
+    col_map, n_valid = bs.valid_cols(good)
+    assert int(n_valid[0]) == B + 1 - 4
+    cm = engine.host(col_map)[0, : n_valid[0]]
+    np.testing.assert_array_equal(cm, np.setdiff1d(np.arange(B + 1), [17, 40, 41, B]))
+    M, tt = design.residual_parts(cov, trt, Nc, good[0])
+    for which, (c_w, se_w) in enumerate(((want[0], want[1]), (want[3], want[4]))):
+        coef, st = bs.contract_resampled(np.arange(1), tt[:1], good, which, np.zeros(1, np.int32), M[None], Nc, rep=rep, bcol=bcol,
+                                         col_map=col_map, n_valid=n_valid)
+        np.testing.assert_allclose(st[0, 0], c_w[0], rtol=1e-9)
+        np.testing.assert_allclose(st[0, 1], se_w[0], rtol=1e-8)
+        assert int(st[0, 2]) == nb - 1
+
+
+def test_c1_pbmc3k_shape_matches_reference(api_c1):
+    """BASELINE.json configs[0]: 2.7k cells x 1.8k genes, 2 groups, 100 bootstraps -- the full API in strict replay against
+    the real reference's output (size factors 1e-12, gene mask bit-exact, coefficients / SE 1e-8, p-values 1e-5)."""
+    from conftest import c1_inputs
+    from scrna_parameter_estimation_amd import AnnDataLite, memento
+
+    g = api_c1
+    X, gid, ng, q = c1_inputs(g)
+    obs = pd.DataFrame({"cond": g["in_cond"].astype(np.int64), "q": np.full(X.shape[0], q)}, index=[f"c{i}" for i in range(X.shape[0])])
+    adata = AnnDataLite(X.astype(np.float32), obs, pd.DataFrame(index=[f"g{i}" for i in range(X.shape[1])]))
+    memento.setup_memento(adata, q_column="q")
+    np.testing.assert_allclose(adata.obs["memento_size_factor"].values, g["size_factor"], rtol=1e-12)
+    memento.create_groups(adata, label_columns=["cond"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    m = adata.uns["memento"]
+    assert m["groups"] == list(g["groups"])
+    np.testing.assert_array_equal(m["overall_gene_filter"], g["overall_gene_filter"])
+    for i, k in enumerate(m["groups"]):
+        np.testing.assert_allclose(m["1d_moments"][k][0], g["mean"][i], rtol=1e-11)
+        np.testing.assert_allclose(m["1d_moments"][k][1], g["var"][i], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(m["1d_moments"][k][2], g["res_var"][i], rtol=1e-8, atol=1e-13, equal_nan=True)
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame(g["covariate"], index=gdf.index, columns=["intercept"])
+    trt = pd.DataFrame(g["treatment"], index=gdf.index, columns=["cond"])
+    np.random.seed(71)
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=100, num_cpus=1, verbose=0, resampling="bootstrap", approx=False,
+                          strict=True)
+    ht = m["1d_ht"]
+    assert len(ht["mean_coef"]) == int(g["overall_gene_filter"].sum()) == 819
+    for k in ["mean_coef", "mean_se", "var_coef", "var_se"]:
+        np.testing.assert_allclose(ht[k], g["ht_" + k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+    for k in ["mean_asl", "var_asl"]:
+        np.testing.assert_allclose(ht[k], g["ht_" + k], rtol=1e-5, atol=1e-12, equal_nan=True, err_msg=k)

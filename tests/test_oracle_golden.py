@@ -163,3 +163,99 @@ def test_regress_2d_resample_rep(regress2d_rr, tag, approx):
     np.testing.assert_allclose(coef, r[f"coef_{tag}"], rtol=1e-9)
     np.testing.assert_allclose(se, r[f"se_{tag}"], rtol=1e-7)
     np.testing.assert_allclose(asl, r[f"asl_{tag}"], rtol=1e-7)
+
+
+def test_corr_matrix_with_nonpositive_variances(corrmat_negvar):
+    """estimator._hyper_corr_symmetric on groups holding genes whose variance estimate is <= 0 (estimator.py:259-268): the
+    reference NaNs only copies, so two negative variances give a finite correlation and the diagonal of such a gene is -1."""
+    from conftest import golden_inputs
+
+    g = corrmat_negvar
+    X, gid, ng, q = golden_inputs(g)
+    Xk = X[:, g["overall_gene_filter"]]
+    seen_neg_pair = False
+    for k in range(ng):
+        sel = np.flatnonzero(gid == k)
+        want = g[f"corr_matrix_{k}"]
+        var = g["var"][k].copy()
+        cm = orc.corr_matrix(Xk[sel], g["size_factor"][sel], g["group_q"][k], var)
+        np.testing.assert_array_equal(var, g["var"][k])                     # no side effect on the stored moments
+        np.testing.assert_array_equal(np.isnan(cm), np.isnan(want))
+        np.testing.assert_allclose(cm, want, rtol=1e-8, atol=1e-12, equal_nan=True)
+        neg = np.flatnonzero(g["var"][k] < 0)
+        if len(neg) >= 2:
+            seen_neg_pair = True
+            assert np.isfinite(want[np.ix_(neg, neg)]).any()                # the case the round-1 oracle got wrong
+    assert seen_neg_pair
+
+
+@pytest.mark.parametrize("tag,approx", [("exact", False), ("approx", True)])
+def test_ht_1d_resample_rep_16_groups(api_rr16, tag, approx):
+    """resample_rep=True through the whole 1D path with 2 x 8 groups (no degenerate resampled column can be expected:
+    P = 3e-5 per column), numeric covariate besides the intercept: the oracle must reproduce the real reference's
+    coefficients, standard errors and p-values WITHOUT any special rule for degenerate columns."""
+    g = api_rr16
+    X, gid, ng, q = golden_inputs(g)
+    keep = g["overall_gene_filter"]
+    mom = dict(mean=g["mean"], res_var=g["res_var"], mv_fit=g["mv_regressor"])
+    np.random.seed(int(g[f"seed_{tag}"]))
+    out = orc.ht_1d(X[:, keep], gid, ng, g["approx_sf"], mom, g["covariate"], g["treatment"], int(g["num_boot"]),
+                    g["group_q"], resampling="bootstrap", approx=approx, resample_rep=True)
+    for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], out):
+        assert np.isfinite(g[f"htrr_{tag}_{k}"]).all()
+        np.testing.assert_allclose(v, g[f"htrr_{tag}_{k}"], rtol=1e-7, equal_nan=True, err_msg=k)
+
+
+def test_ht_2d_resample_rep_16_groups(api_rr16):
+    """ht_2d_moments(resample_rep=True) of the real reference, 16 groups: per pair the three hash uniforms of every live
+    group, then the two np.random.choice draws of _regress_2d (hypothesis_test.py:395-398)."""
+    g = api_rr16
+    X, gid, ng, q = golden_inputs(g)
+    Xk = X[:, g["overall_gene_filter"]].tocsc()
+    i1, i2 = g["pair_idx1"], g["pair_idx2"]
+    sel = [np.flatnonzero(gid == k) for k in range(ng)]
+    Nc = np.array([len(s_) for s_ in sel], dtype=float)
+    asf = [g["approx_sf"][s_] for s_ in sel]
+    np.random.seed(int(g["seed_2d"]))
+    coef, se, asl = (np.full(len(i1), np.nan) for _ in range(3))
+    seen = {}
+    for p in range(len(i1)):
+        a, b = int(i1[p]), int(i2[p])
+        assert a != b
+        key = frozenset((a, b))
+        seen.setdefault(key, []).append(p)
+    for key, plist in seen.items():
+        p = plist[0]
+        a, b = int(i1[p]), int(i2[p])
+        ca = np.asarray(Xk[:, a].todense()).ravel()
+        cb = np.asarray(Xk[:, b].todense()).ravel()
+        tc = g["true_corr"][:, p]
+        res = orc.ht_2d_pair(tc, [ca[s_] for s_ in sel], [cb[s_] for s_ in sel], asf, g["covariate"], g["treatment"], Nc,
+                             int(g["num_boot"]), g["group_q"], resampling="bootstrap", approx=False, resample_rep=True)
+        for pp in plist:
+            coef[pp], se[pp], asl[pp] = [np.atleast_1d(x)[0] for x in res]
+    np.testing.assert_allclose(coef, g["ht2rr_corr_coef"], rtol=1e-7, equal_nan=True)
+    np.testing.assert_allclose(se, g["ht2rr_corr_se"], rtol=1e-7, equal_nan=True)
+    np.testing.assert_allclose(asl, g["ht2rr_corr_asl"], rtol=1e-6, equal_nan=True)
+
+
+def test_c1_pbmc3k_shape_end_to_end(api_c1):
+    """BASELINE.json configs[0]: 2.7k cells x 1.8k genes, 2 groups, 100 bootstraps -- the whole 1D path of the real reference
+    (size factors, moments, filters, exact-ASL hypothesis test) reproduced by the oracle."""
+    from conftest import c1_inputs
+
+    g = api_c1
+    X, gid, ng, q = c1_inputs(g)
+    sf, _, _, _ = orc.setup_size_factors(X, q)
+    np.testing.assert_allclose(sf, g["size_factor"], rtol=1e-12)
+    gq = np.full(ng, q)
+    mom = orc.compute_1d_moments(X, gid, ng, sf, gq)
+    np.testing.assert_array_equal(mom["overall_gene_filter"], g["overall_gene_filter"])
+    np.testing.assert_allclose(mom["mean"], g["mean"], rtol=1e-11)
+    np.testing.assert_allclose(mom["res_var"], g["res_var"], rtol=1e-8, equal_nan=True)
+    approx_sf, _, _ = orc.bin_size_factor(sf)
+    np.random.seed(71)
+    out = orc.ht_1d(X[:, mom["overall_gene_filter"]], gid, ng, approx_sf, mom, g["covariate"], g["treatment"], 100, gq,
+                    resampling="bootstrap", approx=False)
+    for k, v in zip(["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"], out):
+        np.testing.assert_allclose(v, g["ht_" + k], rtol=1e-7, equal_nan=True, err_msg=k)
