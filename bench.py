@@ -6,13 +6,19 @@ group-ordered count blocks already resident in HBM:
     compute_1d_moments  (K1 moments kernel + filters + pooled mean-variance fit)
   + ht_1d_moments       (K5 histograms, bin ordering, numpy-replay bootstrap, fill/log, contraction,
                          p-values incl. the host-side extreme-value tail fits)
-Multi-GPU: genes are sharded -- rank r holds all cells x its own gene shard of the same shape (weak
-scaling, no data-path collective; the pooled fit is one small all-gather).  value = gene-tests of all
-ranks / max-over-ranks time.
+Multi-GPU: genes are sharded, no data-path collective (the size factors are one all-reduce of an N-vector, the pooled
+fit one small all-gather, the results one gather at the end of the step).  ``--scaling strong`` (default): the SAME
+matrix -- BASELINE.json configs[2]: 1M cells x 20k genes -- with rank r holding all cells x genes [r G/N, (r+1) G/N);
+``--scaling weak``: every rank holds a full-size gene shard (N x 20k genes in total).  value = gene-tests of all ranks /
+max-over-ranks time.
 
-Extra objects on the JSON line: "roofline" (the K1 kernel: algorithmic bytes / HIP-event time vs 8 TB/s),
-"bootstrap" (binomial draws/s of the replay kernel), "cpu_baseline" (the CPU oracle on a bounded sample,
-rank 0, N=1 only).
+Extra objects on the JSON line:
+  "roofline"      the K1 kernel on the bytes it really moves (the packed 4 B/entry count blocks): bytes / HIP-event time vs 8 TB/s
+  "roofline_csr"  SURVEY.md section 8(d)'s unit of work -- the CSR's 8 B/nnz + per-cell and output vectors -- over the time of
+                  CSR -> moments for one grouping: ingest (K0: count + layout + scatter, paid once per grouping) + K1
+  "bootstrap"     binomial draws/s of the replay kernel, refilled-chain fraction
+  "cpu_baseline"  the CPU oracle on a bounded sample (rank 0, N=1 only); "reference_cpu": the REAL reference timed in the build
+                  container (baselines/ref_cpu_*.json, other hardware, stated as such)
 """
 
 import argparse
@@ -40,16 +46,19 @@ CONFIGS = {
     "C5s": dict(cells=60_000, genes=3_000, density=0.05, n_cond=101, n_rep=1, num_boot=500),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+TRAFFIC_FILE = "r02_k1_traffic_C3.json"   # this round's PMC record of K1's HBM traffic (tools/k1_traffic.py)
 
 
-def synth_device_csr(cfg, seed, torch):
-    """Gamma-Poisson counts generated ON THE GPU (SURVEY.md section 8d shape); returns engine.DeviceCSR."""
+def synth_device_csr(cfg, seed, torch, gene_lo=0, gene_hi=None):
+    """Gamma-Poisson counts generated ON THE GPU (SURVEY.md section 8d shape); returns engine.DeviceCSR.
+    ``gene_lo/gene_hi``: only that gene range of the matrix (strong scaling: every rank calibrates the SAME 20k-gene
+    expression profile and generates its own columns)."""
     from scrna_parameter_estimation_amd import engine
     from scrna_parameter_estimation_amd.synth import _expected_density
 
     N, G, dens = cfg["cells"], cfg["genes"], cfg["density"]
     rng = np.random.default_rng(seed)
-    mu = rng.lognormal(-2.2, 1.2, size=G)                                  # genes: differ per rank (gene shards)
+    mu = rng.lognormal(-2.2, 1.2, size=G)                                  # weak scaling: differs per rank (own gene shard)
     depth = np.random.default_rng(20250117).lognormal(0.0, 0.35, size=N)   # cells: the SAME cells on every rank
     nodes = np.quantile(depth, (np.arange(64) + 0.5) / 64)
     w = np.full(64, 1.0 / 64)
@@ -61,6 +70,10 @@ def synth_device_csr(cfg, seed, torch):
         else:
             hi = mid
     mu = mu * np.sqrt(lo * hi)
+    if gene_hi is not None:
+        mu = mu[gene_lo:gene_hi]
+        G = len(mu)
+        seed = seed + 7919 * (gene_lo + 1)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
     d_mu = torch.from_numpy(mu.astype(np.float32)).cuda()
@@ -110,6 +123,8 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-baseline-cores", type=int, default=max(1, min(16, os.cpu_count() or 1)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: the same 20k-gene matrix split over the ranks (configs[2]); weak: a full-size gene shard per rank")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -146,11 +161,19 @@ def main():
 
     # ---- untimed preparation: data in HBM, size factors, groups + count blocks -------------------
     t0 = time.time()
-    csr = synth_device_csr(cfg, 20250117 + 1000 * rank, torch)      # every rank: its own gene shard (same cells)
+    G_total = G
+    if args.scaling == "strong" and world > 1:
+        from scrna_parameter_estimation_amd.dist import shard_genes
+        g_lo, g_hi = shard_genes(G_total, rank, world)
+        csr = synth_device_csr(cfg, 20250117, torch, g_lo, g_hi)     # the same matrix on any world size: this rank's gene range
+        G = g_hi - g_lo
+        var = pd.DataFrame(index=[f"g{i}" for i in range(g_lo, g_hi)])
+    else:
+        csr = synth_device_csr(cfg, 20250117 + 1000 * rank, torch)  # weak: every rank its own full-size gene shard (same cells)
+        var = pd.DataFrame(index=[f"r{rank}g{i}" for i in range(G)])
     rng = np.random.default_rng(20250117)                            # identical cell metadata on all ranks
     grp = rng.integers(0, n_groups, size=N)
     obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
-    var = pd.DataFrame(index=[f"r{rank}g{i}" for i in range(G)])
     Xstub = sp.csr_matrix((N, G), dtype=np.float32)                   # shape only: the counts live in HBM
     adata = AnnDataLite(Xstub, obs, var)
     memento.setup_memento(adata, q_column="q", device_csr=csr, comm=comm)
@@ -175,7 +198,8 @@ def main():
         memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
         memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=B, num_cpus=args.num_cpus, verbose=0,
                               resampling="bootstrap", approx=False)
-        return len(adata.uns["memento"]["1d_ht"]["mean_asl"])
+        # multi-GPU: ht_1d_moments ends with the gather, so "1d_ht" holds the tests of ALL ranks; count this rank's own genes
+        return len(state.gene_idx) * trt.shape[1]
 
     def barrier():
         if world > 1:
@@ -200,7 +224,7 @@ def main():
         elapsed, n_tests = float(tt.item()), float(nt.item())
 
     # ---- roofline of the dominant HBM kernel (K1 moments) and bootstrap draw rate, rank 0 --------
-    roof = boot = cpu = None
+    roof = roof_csr = boot = cpu = None
     if rank == 0:
         blocks = state.blocks
         stream = engine._stream()
@@ -227,16 +251,33 @@ def main():
         k1_ms = sorted(passes)[1]
         nbytes = blocks.moments_bytes()
         achieved = nbytes / (k1_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_k1_traffic_C3.json")
-        if args.config == "C3" and os.path.exists(tfile):
-            # PMC counters cannot be read from inside this process: this is the figure recorded with
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction) on the same
-            # shape and kernel -- see profiles/README.md
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if args.config == "C3" and world == 1 and os.path.exists(tfile):
+            # PMC counters cannot be read from inside this process: RECORDED figure of this round, collected with
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction) on the same shape and
+            # kernel by tools/k1_traffic.py -- see profiles/README.md.  null when this round has no such file.
             traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
+            traffic_src = "recorded: profiles/" + TRAFFIC_FILE
         roof = {"kernel": "k_moments1d_sell", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": int(nbytes),
-                "ms_per_launch": round(k1_ms, 4), "ms_per_launch_passes": [round(x, 4) for x in passes], "nnz": int(blocks.nnz_sel)}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_launch": int(nbytes), "bytes_are": "this layout's (4 B per stored entry); see roofline_csr for SURVEY 8(d)'s CSR bytes",
+                "ms_per_launch": round(k1_ms, 4), "ms_per_launch_passes": [round(x, 4) for x in passes], "nnz": int(blocks.nnz_sel),
+                "note": "sustained rate of THIS process (100 untimed launches, median of three 20-launch passes); the plateau differs "
+                        "by up to ~12 % between processes/boxes with identical code (profiles/README.md)"}
+        # SURVEY 8(d)'s unit of work: moments of one grouping straight from the CSR = ingest (K0) + K1, against the CSR's bytes
+        k0 = {}
+        tmp_blocks = engine.CountBlocks(state.csr, state.group_id, n_groups, timing=k0)
+        del tmp_blocks
+        k0_ms = sum(k0.values())
+        nnz = int(state.csr.nnz)
+        csr_bytes = nnz * 8 + (N + 1) * 4 + N * 8 + n_groups * G * 5 * 8
+        t_ms = k0_ms + k1_ms
+        roof_csr = {"kernels": "k_sell_count + k_sell_layout + k_sell_scatter (K0, once per grouping) + k_moments1d_sell", "bound": "hbm",
+                    "achieved": round(csr_bytes / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(csr_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "bytes": int(csr_bytes),
+                    "ms": round(t_ms, 3), "ms_parts": dict({k: round(v, 3) for k, v in k0.items()}, mm_moments1d_sell=round(k1_ms, 4)),
+                    "note": "every later moments pass of the same grouping (setup x2, compute_1d_moments, each bench step) costs K1 only"}
         bs = state.last_bootstrap
         # time one replay launch by itself (HIP events on the launch stream)
         skip = ~((bs.K >= 2))
@@ -249,6 +290,12 @@ def main():
         boot = {"kernel": "k_boot1d_replay(+order,fill)", "binomial_draws": int(draws), "ms": round(ms.value, 2),
                 "draws_per_s": round(draws / (ms.value * 1e-3), 1), "pairs": int((~skip).sum()), "waves": int(bs.n_tiles), "wave_steps_per_replicate": int(bs.tile_ptr[-1]), "K_max": int(bs.K.max()), "K_mean": round(float(bs.K[~skip].mean()), 1),
                 "rng": "numpy-PCG64-replay"}
+        rs = getattr(state, "refill_stats", None)
+        if rs and rs["chains"]:
+            # timed mode = strict=False: invalid replicates refilled on the device; every chain WITHOUT a refill is bit-identical
+            # to the strict (reference-stream) path, which is the mode pinned to the reference's p-values
+            boot["refilled_chain_frac"] = round(rs["chains_refilled"] / rs["chains"], 6)
+            boot["refilled_gene_frac"] = round(rs["genes_refilled"] / max(1, rs["genes"]), 6)
         # fast mode (own RNG streams, replicate-parallel): reported beside the headline, never as `value`
         _lib.call("mm_timer_begin", timer, stream)
         bs.run(skip, r[0], r[1], adata.uns["memento"]["mv_regressor"]["all"], fast=True)
@@ -266,16 +313,29 @@ def main():
         line = {
             "metric": "gene-tests/sec (1D moments + bootstrap hypothesis test)", "value": round(value, 2), "unit": "gene-tests/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {N} cells x {G} genes/GPU, {cfg['density']:.0%} nnz, {n_groups} groups, "
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {N} cells x {G_total if args.scaling == 'strong' else G} genes"
+                                   f"{' in total' if args.scaling == 'strong' else '/GPU'}, {cfg['density']:.0%} nnz, {n_groups} groups, "
                                    f"{B} bootstraps, 1D moments + ht (resampling=bootstrap, approx=False)",
                        "rng": "numpy PCG64 multinomial replay; device refill of invalid replicates", "parallelism": f"genes x{world}",
                        "host_tail_fit_procs": args.num_cpus, "prep_s": round(prep_s, 2)},
-            "roofline": roof, "bootstrap": boot, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_csr": roof_csr, "bootstrap": boot, "cpu_baseline": cpu, "reference_cpu": reference_cpu(args.config),
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def reference_cpu(config):
+    """The REAL reference's own CPU timing on this shape, recorded in the build container by tools/ref_cpu_baseline.py (the
+    reference cannot travel to the GPU box): other hardware, stated as such, printed beside cpu_baseline."""
+    f = os.path.join(ROOT, "baselines", f"ref_cpu_{config}.json")
+    if not os.path.exists(f):
+        return None
+    try:
+        return json.load(open(f))
+    except Exception:
+        return None
 
 
 _CPU = {}

@@ -63,6 +63,16 @@ int mm_debug_read_probe(const void *d_src, int64_t n_bytes, int32_t n_workgroups
 int mm_csr_rowsum(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows,
                   const uint8_t *d_gene_mask /* NULL = all genes */, double *d_out, void *stream);
 
+/* ---- gene sharding on the device (multi-GPU: every rank keeps all cells x its own gene range) --------------------
+ * replaces the host-side X[:, lo:hi] (scipy fancy indexing, O(nnz)) in front of the reference's per-gene fan-out
+ * (memento/main.py:379-397).  mm_csr_colcount: d_row_nnz[r] = entries of row r with col_lo <= column < col_hi.
+ * The caller builds d_out_indptr as the exclusive scan of d_row_nnz (n_rows + 1 values); mm_csr_colsplit then writes those
+ * entries, in their original order and with column - col_lo, to d_out_indices / d_out_data. */
+int mm_csr_colcount(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int32_t col_lo, int32_t col_hi,
+                    int64_t *d_row_nnz, void *stream);
+int mm_csr_colsplit(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows, int32_t col_lo,
+                    int32_t col_hi, const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_data, void *stream);
+
 /* ---- K0: ingest = CSR -> group-ordered SELL count blocks --------------------------------------
  * replaces util._select_cells(adata, group) = adata.X[mask].tocsc() per group
  *   memento/util.py:8-13, memento/main.py:128

@@ -26,6 +26,53 @@ __global__ __launch_bounds__(256) void k_csr_rowsum(const int64_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gene sharding on the device (multi-GPU, one process per GPU: every rank keeps all cells x ITS genes): the column range
+// [lo, hi) of the resident CSR as a new CSR with renumbered columns.  Replaces the host-side X[:, lo:hi] (scipy, O(nnz))
+// the sharded drivers had to do before.  Pass 1 counts per row, the caller turns the counts into row pointers (exclusive
+// scan), pass 2 writes the surviving entries in their original order (ballot compaction, one wave per row).
+__global__ __launch_bounds__(256) void k_csr_colcount(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      int64_t n_rows, int32_t lo, int32_t hi, int64_t *__restrict__ row_nnz) {
+  int lane = mm_lane();
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n_rows; r += nwaves) {
+    int64_t s = indptr[r], e = indptr[r + 1];
+    int cnt = 0;
+    for (int64_t i = s + lane; i < e; i += 64) {
+      int g = indices[i];
+      cnt += (g >= lo && g < hi) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) row_nnz[r] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_csr_colsplit(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      const float *__restrict__ data, int64_t n_rows, int32_t lo, int32_t hi,
+                                                      const int64_t *__restrict__ out_indptr, int32_t *__restrict__ out_indices,
+                                                      float *__restrict__ out_data) {
+  int lane = mm_lane();
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n_rows; r += nwaves) {
+    int64_t s = indptr[r], e = indptr[r + 1];
+    int64_t o = out_indptr[r];
+    for (int64_t i0 = s; i0 < e; i0 += 64) {   // wave-uniform trip count: every lane reaches the ballot
+      int64_t i = i0 + lane;
+      int g = i < e ? indices[i] : -1;
+      bool keep = g >= lo && g < hi;
+      uint64_t bal = __ballot(keep);
+      if (keep) {
+        int64_t pos = o + __popcll(bal & ((1ull << lane) - 1ull));
+        out_indices[pos] = g - lo;
+        out_data[pos] = data[i];
+      }
+      o += __popcll(bal);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K0 step 1: nnz per (block, gene) with LDS counters; validates the counts.
 #define CNT_TILE 32768
 __global__ __launch_bounds__(1024) void k_sell_count(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
@@ -206,6 +253,30 @@ int mm_csr_rowsum(const int64_t *d_indptr, const int32_t *d_indices, const float
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_csr_rowsum, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_data, n_rows,
                      d_gene_mask, d_out);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_csr_colcount(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int32_t col_lo, int32_t col_hi,
+                    int64_t *d_row_nnz, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_row_nnz && n_rows >= 0 && col_lo >= 0 && col_hi >= col_lo);
+  if (n_rows == 0) return MM_OK;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_csr_colcount, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, n_rows, col_lo,
+                     col_hi, d_row_nnz);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_csr_colsplit(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows, int32_t col_lo,
+                    int32_t col_hi, const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_data, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_data && d_out_indptr && d_out_indices && d_out_data && n_rows >= 0 && col_lo >= 0 && col_hi >= col_lo);
+  if (n_rows == 0) return MM_OK;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_csr_colsplit, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_data, n_rows,
+                     col_lo, col_hi, d_out_indptr, d_out_indices, d_out_data);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

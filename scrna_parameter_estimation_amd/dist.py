@@ -6,6 +6,14 @@ remain, both outside the O(nnz) kernels:
   * per-cell totals for the size factors  -> all-reduce(sum) of an N-vector  (estimator.py:65, :73)
   * the pooled mean-variance fit          -> all-gather of per-gene moments   (main.py:232-245, :68-71)
 They run over torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+One-call use (every rank runs the same script under torchrun, the reference's fan-out + scatter-back of
+memento/main.py:379-412 spread over GPUs):
+    comm = Comm()
+    memento.setup_memento(adata, 'q', comm=comm, shard=True)   # full X on every rank -> device-side column split
+    memento.create_groups(adata, [...]); memento.compute_1d_moments(adata)
+    memento.ht_1d_moments(adata, covariate=..., treatment=..., ...)   # ends with the gather below
+    memento.get_1d_ht_result(adata)                            # the FULL table, gene order of the unsharded run, on every rank
 """
 
 import numpy as np
@@ -43,6 +51,34 @@ class Comm:
         out = [torch.zeros_like(buf) for _ in range(self.world)]
         dist.all_gather(out, buf)
         return np.concatenate([o[:s].cpu().numpy() for o, s in zip(out, sizes)])
+
+
+    def allgather_objects(self, obj):
+        """Small python objects (dicts of numpy arrays, name lists) from every rank, in rank order."""
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+def gather_1d_ht(comm, names, out):
+    """Result gather of the gene-sharded 1D test: every rank contributes its genes' flat result vectors (gene-major x treatment,
+    reference order memento/main.py:399-404) and the names of its kept genes; since the shards are contiguous gene ranges in
+    rank order, the concatenation in rank order IS the unsharded run's ordering.  Returns (all names, dict of full vectors)."""
+    parts = comm.allgather_objects({"names": list(names), "out": {k: np.asarray(v) for k, v in out.items()}})
+    all_names = [n for p_ in parts for n in p_["names"]]
+    full = {k: np.concatenate([p_["out"][k] for p_ in parts]) for k in out}
+    return all_names, full
+
+
+def gather_pair_results(comm, positions, values, n_total):
+    """2D counterpart: ``values`` (dict of arrays aligned with this rank's pair block) and the block's ``positions`` in the
+    caller's pair list (from ``shard_pairs``) -> dict of full-length arrays in the caller's order, on every rank."""
+    parts = comm.allgather_objects({"pos": np.asarray(positions, dtype=np.int64), "val": {k: np.asarray(v) for k, v in values.items()}})
+    full = {k: np.full(n_total, np.nan) for k in values}
+    for p_ in parts:
+        for k in values:
+            full[k][p_["pos"]] = p_["val"][k]
+    return full
 
 
 def shard_genes(n_genes, rank, world):

@@ -85,7 +85,8 @@ class DeviceCSR:
 
     @classmethod
     def from_device(cls, indptr, indices, data, shape):
-        """Wrap CSR arrays that already live in HBM (torch cuda tensors: int64 / int32 / float32)."""
+        """Wrap CSR arrays that already live in HBM (torch cuda tensors: int64 / int32 / float32).  Precondition (checked by
+        the ingest kernel, which raises): every stored value is a positive integer count -- no explicitly stored zeros."""
         torch = _torch()
         assert indptr.dtype == torch.int64 and indices.dtype == torch.int32 and data.dtype == torch.float32
         self = cls.__new__(cls)
@@ -102,6 +103,11 @@ class DeviceCSR:
         if not X.has_canonical_format:
             X = X.copy()
             X.sum_duplicates()
+        if X.nnz and (X.data == 0).any():
+            # explicitly stored zeros (common after subsetting or arithmetic on adata.X; the reference accepts any scipy CSR,
+            # main.py:44): they carry no count, drop them from the device copy
+            X = X.copy()
+            X.eliminate_zeros()
         self.shape = X.shape
         self.nnz = int(X.nnz)
         data = X.data
@@ -117,6 +123,25 @@ class DeviceCSR:
     @property
     def nbytes(self):
         return self.indptr.numel() * 8 + self.indices.numel() * 4 + self.data.numel() * 4
+
+    def colsplit(self, lo, hi):
+        """The gene (column) range [lo, hi) as a new device CSR with columns renumbered from 0 -- the device-side replacement
+        of the host ``X[:, lo:hi]`` in front of gene-sharded multi-GPU runs (mm_csr_colcount + mm_csr_colsplit)."""
+        torch = _torch()
+        lo, hi = int(lo), int(hi)
+        if not (0 <= lo <= hi <= self.shape[1]):
+            raise ValueError("column range out of bounds")
+        n = self.shape[0]
+        row_nnz = empty((max(1, n),), torch.int64)
+        _lib.call("mm_csr_colcount", P(self.indptr), P(self.indices), n, lo, hi, P(row_nnz), _stream())
+        indptr = zeros((n + 1,), torch.int64)
+        if n:
+            indptr[1:] = torch.cumsum(row_nnz[:n], 0)
+        nnz = int(indptr[-1].item())
+        indices = empty((max(1, nnz),), torch.int32)
+        data = empty((max(1, nnz),), torch.float32)
+        _lib.call("mm_csr_colsplit", P(self.indptr), P(self.indices), P(self.data), n, lo, hi, P(indptr), P(indices), P(data), _stream())
+        return DeviceCSR.from_device(indptr, indices[:nnz], data[:nnz], (n, hi - lo))
 
     def rowsum(self, gene_mask=None):
         """K3: per-cell sums, optionally over a gene mask (estimator.py:65, :73)."""
@@ -160,8 +185,11 @@ def plan_blocks(group_id, n_groups, block_cells=BLOCK_CELLS):
 class CountBlocks:
     """K0 result: the group-ordered SELL-64x4 count blocks living in HBM (see include/memento_hip.h)."""
 
-    def __init__(self, csr, group_id, n_groups):
+    def __init__(self, csr, group_id, n_groups, timing=None):
+        """``timing``: an optional dict that receives the HIP-event time (ms) of each of the three K0 launches
+        (bench.py's CSR -> moments roofline; the launches are otherwise untimed)."""
         torch = _torch()
+        call = _lib.call if timing is None else (lambda name, *a: _timed_call(timing, name, *a))
         self.G = int(csr.shape[1])
         self.n_groups = int(n_groups)
         (self.cell_order, self.blk_cell0, self.blk_group, self.grp_blk0, self.grp_ncells) = plan_blocks(group_id, n_groups)
@@ -176,7 +204,7 @@ class CountBlocks:
         self.d_grp_blk0 = dev(self.grp_blk0)
         blk_cnt = zeros((nb, G), torch.int16)
         status = zeros((1,), torch.int32)
-        _lib.call("mm_sell_count", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
+        call("mm_sell_count", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
                   P(blk_cnt), P(status), s)
         if int(status.item()) != 0:
             raise ValueError(f"count matrix must hold positive integer counts <= {MAX_COUNT} with valid column indices")
@@ -187,7 +215,7 @@ class CountBlocks:
         self.item_ptr = empty((nb, ns + 1), torch.int32)
         blk_rows = empty((nb,), torch.int64)
         blk_items = empty((nb,), torch.int32)
-        _lib.call("mm_sell_layout", P(blk_cnt), nb, G, P(self.rank), P(self.perm), P(self.slice_w), P(self.slice_ptr),
+        call("mm_sell_layout", P(blk_cnt), nb, G, P(self.rank), P(self.perm), P(self.slice_w), P(self.slice_ptr),
                   P(self.item_ptr), P(blk_rows), P(blk_items), s)
         rows = host(blk_rows)
         items = host(blk_items).astype(np.int64)
@@ -198,7 +226,7 @@ class CountBlocks:
         self.blk_base = dev(base[:-1])
         self.blk_item_base = dev(ibase[:-1])
         self.ent = zeros((max(1, self.total_rows) * 256,), torch.int32)
-        _lib.call("mm_sell_scatter", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
+        call("mm_sell_scatter", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
                   P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), s)
         self.blk_cnt = host(blk_cnt, np.uint16)            # nnz per (block, gene), host copy [nb][G]
         self.nnz_sel = int(self.blk_cnt.astype(np.int64).sum())
@@ -235,6 +263,19 @@ class CountBlocks:
                   P(self.item_ptr), P(self.blk_item_base), P(self.d_grp_blk0), self.n_groups, self.G, P(out_S), P(out_sx),
                   P(out_mx), _stream())
         return host(out_S), host(out_sx, np.uint64), host(out_mx, np.uint32)
+
+
+def _timed_call(timing, name, *args):
+    """_lib.call bracketed by HIP events on the launch stream (last argument); elapsed ms -> timing[name]."""
+    t = c_void_p()
+    ms = ctypes.c_float()
+    _lib.call("mm_timer_create", ctypes.byref(t))
+    _lib.call("mm_timer_begin", t, args[-1])
+    _lib.call(name, *args)
+    _lib.call("mm_timer_end", t, args[-1])
+    _lib.call("mm_timer_elapsed_ms", t, ctypes.byref(ms))
+    _lib.call("mm_timer_destroy", t)
+    timing[name] = timing.get(name, 0.0) + float(ms.value)
 
 
 def _tiles_from_lanes(lanes, n_act):
@@ -662,6 +703,13 @@ def pair_cross(cols, col1, col2, inv_sf_cells):
     return res
 
 
+def pair_table_bytes(maxx, genes, col1, col2, n_groups, n_bins):
+    """Bytes of the dense (x_i, x_j, sf_bin) histogram tables Bootstrap2D allocates, per pair (all groups): used to size pair
+    chunks against the free HBM (a pair of highly expressed genes costs tens of MB per group)."""
+    cap = np.asarray(maxx, dtype=np.int64)[:, np.asarray(genes, dtype=np.int64)] + 1            # [group][column slot]
+    return (cap[:, np.asarray(col1, dtype=np.int64)] * cap[:, np.asarray(col2, dtype=np.int64)]).sum(axis=0) * int(n_bins) * 4
+
+
 class Bootstrap2D:
     """2D analogue of Bootstrap1D for a list of gene pairs (column slots of a GeneColumns store):
     (x_i, x_j, sf_bin) histograms -> bins -> replay order -> replay bootstrap of the correlation."""
@@ -710,6 +758,30 @@ class Bootstrap2D:
         bi, xi, xj = np.nonzero(tab)
         return bi, xi, xj, tab[bi, xi, xj]
 
+    def _order_on_host(self, q, ra, rb, r0, slot, tile_ptr, ops):
+        """Replay order + bootstrap operands of ONE (pair, group) with more bins than the in-LDS sort holds, computed on the host
+        with the same arithmetic as k_bins_order2d: code = (x_i*r[0] + x_j*r[1]) + r0*approx_sf ascending (bootstrap.py:62-67)."""
+        bi, xi, xj, mu = self.bins_of(q)
+        code = (xi.astype(np.float64) * ra + xj.astype(np.float64) * rb) + r0 * self.sf_table[bi]
+        o = np.argsort(code, kind="stable")
+        if len(o) > 1 and (np.diff(code[o]) == 0).any():
+            raise NotImplementedError("two bins of one pair collided in the replay hash (np.unique would merge them)")
+        bi, xi, xj, mu = bi[o], xi[o].astype(np.float64), xj[o].astype(np.float64), mu[o].astype(np.float64)
+        pix = mu / float(self.blocks.grp_ncells[q % self.ng])
+        rem = np.empty_like(pix)
+        acc = 1.0
+        for k in range(len(pix)):      # sequential rounding, exactly like numpy's remaining_p
+            rem[k] = acc
+            acc -= pix[k]
+        pk = pix / rem
+        peff = np.where(pk <= 0.5, pk, 1.0 - pk)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lq = np.log(1.0 - peff)
+        sf = self.sf_table[bi]
+        idx = dev((int(tile_ptr[slot >> 6]) + np.arange(len(pk), dtype=np.int64)) * 64 + (slot & 63))
+        for arr, vals in zip(ops, (pk, lq, xi, xj, 1.0 / sf, 1.0 / (sf * sf))):
+            arr[idx] = dev(vals)
+
     def run(self, skip, r1a, r1b, r0, true_corr, pcg_seed=5, target_waves=None):
         """All arrays are indexed by q = sorted_pair*n_groups + group (see ``self.order``).  Leaves the
         replicate correlations in self.yc [n_q][B+1] (column 0 = true correlation)."""
@@ -718,8 +790,6 @@ class Bootstrap2D:
         ng, B, ld = self.ng, self.B, self.ld
         active = (~np.asarray(skip, dtype=bool)) & (self.K >= 1)
         act = np.flatnonzero(active)
-        if len(act) and (self.K[act] > ORDER_BIG_CAP_2D).any():
-            raise NotImplementedError(f"a (pair, group) has more than {ORDER_BIG_CAP_2D} unique bins")
         order = act[np.argsort(-self.K[act], kind="stable")]
         slot_of, n_tiles = pack_lanes(self.K[order], PACK_WAVES if target_waves is None else target_waves)
         slot_of = pair_tiles(slot_of, n_tiles, self.K[order])
@@ -740,7 +810,10 @@ class Bootstrap2D:
         d_ra, d_rb, d_r0 = dev(np.asarray(r1a, np.float64)), dev(np.asarray(r1b, np.float64)), dev(np.asarray(r0, np.float64))
         d_sf, d_nc = dev(self.sf_table), dev(self.blocks.grp_ncells.astype(np.float64))
         small = order[self.K[order] <= ORDER_SMALL_CAP]
-        big = order[self.K[order] > ORDER_SMALL_CAP]
+        big = order[(self.K[order] > ORDER_SMALL_CAP) & (self.K[order] <= ORDER_BIG_CAP_2D)]
+        huge = order[self.K[order] > ORDER_BIG_CAP_2D]
+        for q in huge:   # more bins than the in-LDS sort holds (two highly expressed genes): ordered on the host, like the 1D path
+            self._order_on_host(int(q), float(r1a[q]), float(r1b[q]), float(r0[q]), int(pair_slot[q]), tile_ptr, ops)
         for lst, is_big in ((small, 0), (big, 1)):
             if len(lst):
                 d_lst = dev(lst)

@@ -78,18 +78,58 @@ def _moments_from_sums(S, n_obs, q):
     return mean, var
 
 
+def _plain_means(blocks, sumx, n_cells, thresh, kind):
+    """Plain per-group mean count of every gene, as the reference's scipy calls round it, for the `mean < thresh` gene filters
+    (main.py:67 on the CSR of all cells, :201-203 on a group's CSC copy).
+
+    The device returns the exact integer sum of the counts, so mean = sumx / n is exact to one rounding -- but scipy computes
+    sum_c fl(x_c * (1/n)) (sequentially in cell order for a CSR, first + pairwise(rest) for a CSC), which lands a few ulp away.
+    That only matters when sumx / n IS the threshold (e.g. 189 counts in 2,700 cells = 0.07): for such genes -- and only for
+    them -- the gene's counts are pulled from the count blocks in cell order and summed the way scipy does, so the filter
+    decides exactly like the reference.  Returns float64 [n_groups][G]."""
+    n_cells = np.asarray(n_cells, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = sumx.astype(np.float64) / n_cells[:, None]
+    near = np.abs(mean - thresh) <= 1e-9 * abs(thresh)
+    if not near.any():
+        return mean
+    genes = np.flatnonzero(near.any(axis=0))
+    cols = engine.GeneColumns(blocks, genes)
+    data = engine.host(cols.cols, np.uint32)
+    ptr = engine.host(cols.col_ptr)
+    for gi, m_ in zip(*np.nonzero(near[:, genes])):
+        parts = []
+        for b in range(int(blocks.grp_blk0[gi]), int(blocks.grp_blk0[gi + 1])):
+            e = data[int(ptr[b, m_]):int(ptr[b, m_ + 1])]
+            e = e[np.argsort(e & (engine.BLOCK_CELLS - 1), kind="stable")]        # cell order inside the block
+            parts.append((e >> 13).astype(np.float64))
+        v = np.concatenate(parts) if parts else np.zeros(0)
+        v = np.ascontiguousarray(v * (1.0 / n_cells[gi]))
+        if len(v) == 0:
+            val = 0.0
+        elif kind == 'csr':
+            val = float(np.cumsum(v)[-1])                    # csc_matvec of the transpose: sequential in cell order
+        else:
+            val = float(np.add.reduceat(v, [0])[0])          # _minor_reduce: first + pairwise(rest)
+        mean[gi, genes[m_]] = val
+    return mean
+
+
 # ----------------------------------------------------------------------------------------------
 # setup_memento / create_groups
 # ----------------------------------------------------------------------------------------------
 
 
 def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_percent=0.1, shrinkage=0.5, num_bins=30,
-                  estimator_type='hyper_relative', *, device_csr=None, comm=None):
+                  estimator_type='hyper_relative', *, device_csr=None, comm=None, shard=False):
     """Compute size factors and the all-cell moments (reference: memento/main.py:26-91).
 
     Extensions: ``device_csr`` -- an ``engine.DeviceCSR`` already resident in HBM (``adata.X`` is then only
     used for its shape); ``comm`` -- a ``dist.Comm`` when the GENES are sharded over ranks (every rank holds
-    all cells x its gene shard): per-cell totals are all-reduced so every rank gets the global size factors."""
+    all cells x its gene shard): per-cell totals are all-reduced so every rank gets the global size factors.
+    ``shard=True`` (with ``comm``): ``adata`` holds ALL genes on every rank; this rank's contiguous gene range is cut out
+    of the resident CSR on the device (mm_csr_colsplit) -- no host-side ``X[:, lo:hi]`` -- and the later calls work on
+    that shard (``adata`` itself is left whole; ``uns['memento']['gene_list']`` etc. name the shard's genes)."""
     if not inplace:
         adata = adata.copy()
     assert adata.obs[q_column].max() < 1
@@ -108,6 +148,17 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
     st.comm = comm
     N, G = adata.shape
     assert tuple(st.csr.shape) == (N, G)
+    names0 = np.asarray(adata.var.index)
+    st.shard = None
+    if shard:
+        if comm is None:
+            raise ValueError("shard=True needs comm")
+        from ..dist import shard_genes
+        lo, hi = shard_genes(G, comm.rank, comm.world)
+        st.csr = st.csr.colsplit(lo, hi)             # device-side column split; the full CSR is released
+        st.shard = (lo, hi)
+        st.var_names = names0 = names0[lo:hi]
+        G = hi - lo
     st.gene_idx = np.arange(G)
     naive = st.csr.rowsum()                                                   # estimator.py:64-69
     if comm is not None:
@@ -117,7 +168,7 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
         S, sumx, _ = blocks_all.moments(1.0 / naive)
     all_m, all_v = _moments_from_sums(S[:, 0], N, m['all_q'])                 # main.py:62-66
     all_m = all_m.copy()
-    all_m[(sumx[0].astype(np.float64) / N) < filter_mean_thresh] = 0          # main.py:67
+    all_m[_plain_means(blocks_all, sumx, [N], filter_mean_thresh, 'csr')[0] < filter_mean_thresh] = 0   # main.py:67
     if comm is None:
         all_rv = _res_var(all_m, all_v, _mv_fit(all_m, all_v))                # main.py:68
         rv_ulim = np.quantile(all_rv[np.isfinite(all_rv)], trim_percent)      # main.py:71
@@ -129,7 +180,7 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
         all_rv = _res_var(all_m, all_v, fit0)
     all_rv[~np.isfinite(all_rv)] = np.inf
     mask = all_rv < rv_ulim                                                   # main.py:73
-    m['least_variable_genes'] = adata.var.index[mask].tolist()
+    m['least_variable_genes'] = names0[mask].tolist()
     nrc = st.csr.rowsum(mask)                                                 # estimator.py:73
     if comm is not None:
         nrc = comm.allreduce_sum(nrc)
@@ -233,18 +284,21 @@ def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=Tru
     gq = np.array([m['group_q'][g] for g in groups])
     S, sumx, maxx = st.blocks.moments(1.0 / adata.obs['memento_size_factor'].values)          # K1+K2
     cur = st.gene_idx                                    # columns of the device blocks that adata currently holds
+    names_cur = _var_names(adata)
+    if getattr(st, 'shard', None) is not None:
+        subset_var = False                               # adata holds all genes of all ranks; only the shard's names move
     mean = S[0][:, cur] / Nc[:, None]
     var = S[1][:, cur] / Nc[:, None] - (1 - gq)[:, None] * S[2][:, cur] / Nc[:, None] - mean ** 2
     if m['estimator_type'] == 'mean_only':                                                     # estimator.py:188-204
         mean, var = mean + 1, np.ones(mean.shape) * 10
     st.sumx, st.maxx, st.S = sumx, maxx, S
-    obs_mean = sumx[:, cur].astype(np.float64) / Nc[:, None]                                   # main.py:201
+    obs_mean = _plain_means(st.blocks, sumx, Nc, m['filter_mean_thresh'], 'csc')[:, cur]      # main.py:201
     gene_filter = (obs_mean > m['filter_mean_thresh']) & (var > 0)                             # main.py:202-203
     gene_rv_filter = maxx[:, cur] >= 2                                                         # main.py:206-207
     m['gene_filter'] = {g: gene_filter[i] for i, g in enumerate(groups)}
     overall = gene_filter.mean(axis=0) > min_perc_group                                        # main.py:210-212
     m['overall_gene_filter'] = overall
-    m['gene_list'] = adata.var.index[overall].tolist()
+    m['gene_list'] = names_cur[overall].tolist()
     if filter_genes:                                                                           # main.py:219-229
         mean, var, gene_rv_filter = mean[:, overall], var[:, overall], gene_rv_filter[:, overall]
         st.gene_idx = cur[overall]
@@ -253,7 +307,7 @@ def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=Tru
         if subset_var:
             adata._inplace_subset_var(overall)
         else:
-            st.var_names = np.asarray(adata.var.index)[overall]
+            st.var_names = names_cur[overall]
     m['gene_rv_filter'] = {g: gene_rv_filter[i] for i, g in enumerate(groups)}
     fm = np.concatenate([mean[i][gene_rv_filter[i]] for i in range(ng)])
     fv = np.concatenate([var[i][gene_rv_filter[i]] for i in range(ng)])
@@ -424,6 +478,14 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             draw_stream(0)
             n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
             bad_fill = (n_inv < 0).any(axis=1)
+            # how much of the result depends on the device refill (strict=True replays the reference's own _fill draws instead):
+            # chains / genes with at least one refilled replicate -- all others are bit-identical to the strict path
+            refilled = (n_inv > 0).any(axis=1) & ~skip
+            rs = st.refill_stats
+            rs['chains'] += int(((~skip) & (bs.K >= 2)).sum())
+            rs['chains_refilled'] += int(refilled.sum())
+            rs['genes'] += G
+            rs['genes_refilled'] += int(refilled.reshape(G, ng).any(axis=1).sum())
         else:
             def strict_pass():
                 """One sequential replay of the reference's global-stream consumption over all genes (speculate, then roll back to
@@ -559,6 +621,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         return out
 
     G_all = len(st.gene_idx)
+    st.refill_stats = dict(chains=0, chains_refilled=0, genes=0, genes_refilled=0)
     if max_rows is None:                       # replicate buffers sized to the free HBM (288 GB on MI355X)
         max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
     chunk = G_all if strict else max(1, int(max_rows) // max(1, ng))   # strict replay is sequential over all genes
@@ -566,6 +629,12 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     keys = ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')
     out = {k: (np.concatenate([p_[k] for p_ in parts]) if parts else np.zeros(0)) for k in keys}
     m['1d_ht'] = {}
+    comm = getattr(st, 'comm', None)
+    if comm is not None and comm.world > 1:
+        # gene-sharded run: scatter-back of the reference (main.py:399-412) across ranks -- every rank ends with the flat result
+        # vectors of ALL genes in the unsharded run's order, plus the gene names they belong to
+        from ..dist import gather_1d_ht
+        m['1d_ht']['gene_names'], out = gather_1d_ht(comm, names, out)
     if treatment_for_gene is not None:
         m['1d_ht']['treatment_for_gene'] = treatment_for_gene
     m['1d_ht']['treatment'] = treatment
@@ -634,6 +703,7 @@ def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', f
             cols[tag + '_se'].append(stt[:, 1])
             cols[tag + '_asl'].append(p)
     out = {k: (np.concatenate(v) if v else np.zeros(0)) for k, v in cols.items()}
+    st.last_bootstrap, st.last_chunk = bs, ((g0, g1) if G_all else (0, 0))       # diagnostics / tests: the last gene chunk's replicate rows
     m['1d_ht_vs_control'] = dict(out, control=groups[ctrl], groups=[groups[j] for j in others])
     df = pd.DataFrame({'gene': np.repeat(names, len(others)), 'group': np.tile([groups[j] for j in others], G_all)})
     df['de_coef'], df['de_se'], df['de_pval'] = out['mean_coef'], out['mean_se'], out['mean_asl']
@@ -793,8 +863,19 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     if max_rows is None:
         max_rows = min(1 << 19, engine.auto_max_rows(num_boot + 1, arrays=1))   # also bounds the per-pair 2D tables
     chunk = max(1, int(max_rows) // max(1, ng))
-    for lo in range(0, P_, chunk):
-        hi = min(P_, lo + chunk)
+    # chunk boundaries: at most ``chunk`` pairs (replicate rows) AND at most a third of the free HBM in histogram tables
+    tab_bytes = engine.pair_table_bytes(st.maxx, st.cols.genes, c1, c2, ng, len(st.sf_table)) if P_ else np.zeros(0, dtype=np.int64)
+    budget = max(1 << 28, engine._torch().cuda.mem_get_info()[0] // 3)
+    bounds, acc = [0], 0
+    for k in range(P_):
+        if k - bounds[-1] >= chunk or (acc + int(tab_bytes[k]) > budget and k > bounds[-1]):
+            bounds.append(k)
+            acc = 0
+        acc += int(tab_bytes[k])
+    bounds.append(P_)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        if hi <= lo:
+            continue
         n_ch = hi - lo
         bs = engine.Bootstrap2D(st.cols, c1[lo:hi], c2[lo:hi], st.maxx, st.sf_bin, st.sf_table, gq, num_boot)
         so = bs.order                                     # device pair order (sorted by left column)
@@ -871,6 +952,7 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 corr_coef[cc], corr_se[cc], corr_asl[cc] = stt[k, 0], stt[k, 1], pvals[k]
     m['2d_ht'] = {'treatment': treatment, 'covariate': covariate, 'corr_coef': corr_coef, 'corr_se': corr_se, 'corr_asl': corr_asl}
     st.last_bootstrap2d = bs
+    st.last_chunk2d = (bounds[-2], bounds[-1]) if P_ else (0, 0)                   # diagnostics / tests: pair range of the last chunk
     if not inplace:
         return adata
 
@@ -919,7 +1001,7 @@ def get_1d_moments(adata, groupby=None):
 def get_1d_ht_result(adata):
     """DataFrame of DE / DV coefficients, standard errors and p-values (reference: memento/main.py:635-655)."""
     ht = adata.uns['memento']['1d_ht']
-    names = _var_names(adata)
+    names = ht['gene_names'] if 'gene_names' in ht else _var_names(adata)       # 'gene_names': gathered multi-GPU result
     if 'treatment_for_gene' in ht:
         pairs = [(g, t) for g in names for t in ht['treatment_for_gene'][g]]
     else:

@@ -177,6 +177,25 @@ assert np.array_equal(gm, mean) and np.array_equal(gv, var)
 assert np.allclose(_mv_fit(gm, gv), _mv_fit(mean, var), rtol=0, atol=0)   # pooled fit identical on every rank
 e = c.allgather_concat(np.zeros(0) if rank == 0 else np.ones(3))         # ragged / empty shard
 assert e.tolist() == [1.0, 1.0, 1.0]
+# result gather of the gene-sharded 1D test: kept genes differ per shard, two result vectors, a gene with two tests
+from scrna_parameter_estimation_amd.dist import gather_1d_ht, gather_pair_results, shard_pairs
+names_all = [f"g{i}" for i in range(G)]
+kept = rng.random(G) < 0.6
+ntest = np.where(np.arange(G) %% 5 == 0, 2, 1)                            # treatment_for_gene-like: some genes carry two tests
+coef_all = np.concatenate([np.full(ntest[i], mean[i]) for i in range(G) if kept[i]])
+mine = [i for i in range(lo, hi) if kept[i]]
+out = {"mean_coef": np.concatenate([np.full(ntest[i], mean[i]) for i in mine]) if mine else np.zeros(0),
+       "mean_asl": np.concatenate([np.full(ntest[i], var[i]) for i in mine]) if mine else np.zeros(0)}
+gn, full = gather_1d_ht(c, [names_all[i] for i in mine], out)
+assert gn == [names_all[i] for i in range(G) if kept[i]]
+assert np.array_equal(full["mean_coef"], coef_all) and len(full["mean_asl"]) == len(coef_all)
+# 2D: pair blocks from shard_pairs, results back in the caller's order on every rank
+pairs = [(names_all[int(a)], names_all[int(b)]) for a, b in rng.integers(0, G, size=(37, 2))]
+blk, pos = shard_pairs(pairs, rank, world)
+assert [pairs[i] for i in pos] == blk
+val = np.array([float(int(a[1:]) * 1000 + int(b[1:])) for a, b in blk])
+full2 = gather_pair_results(c, pos, {"corr_coef": val}, len(pairs))
+assert np.array_equal(full2["corr_coef"], np.array([float(int(a[1:]) * 1000 + int(b[1:])) for a, b in pairs]))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

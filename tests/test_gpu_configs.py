@@ -1,0 +1,228 @@
+"""BASELINE.json configs[3] (2D, 2000 x 2000 gene pairs over 8 GPUs: ONE GPU's true share = 500,000 pairs on 500k cells, 1,000
+bootstraps) and configs[4] (Perturb-seq: 200k cells x 15k genes, 500 guide groups x 1 control, 5,000 bootstraps) at full size
+on one MI355X: size-independent invariants over everything, plus oracle spot checks of ~20 chains / contrasts each.  And the
+reference's own per-guide loop (fixture from the real reference) against the batched guide-vs-control call."""
+
+import time
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_columns(csr, genes, torch):
+    import bench
+
+    return bench.sample_columns(csr, genes, torch)
+
+
+def test_c4_one_gpu_share_of_2000x2000_pairs():
+    """configs[3] per-GPU share: 250 x 2000 = 500,000 gene pairs, 500k cells, 2 groups, 1,000 bootstraps."""
+    import torch
+
+    import bench
+    from oracle import memento_oracle as orc
+    from scrna_parameter_estimation_amd import AnnDataLite, engine, memento
+
+    cells, genes, B = 500_000, 8_000, 1_000
+    csr = bench.synth_device_csr(dict(cells=cells, genes=genes, density=0.08), 3, torch)
+    rng = np.random.default_rng(1)
+    grp = rng.integers(0, 2, size=cells)
+    obs = pd.DataFrame({"cond": grp, "q": np.full(cells, 0.07)})
+    adata = AnnDataLite(sp.csr_matrix((cells, genes), dtype=np.float32), obs, pd.DataFrame(index=[f"g{i}" for i in range(genes)]))
+    memento.setup_memento(adata, q_column="q", device_csr=csr)
+    memento.create_groups(adata, label_columns=["cond"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+    m = adata.uns["memento"]
+    st = m["_hip"]
+    names = memento.main._var_names(adata)
+    assert len(names) >= 2250, len(names)                       # 2000 x 2000 needs 4000; this GPU's share: 250 left x 2000 right
+    left, right = names[:250], names[250:2250]
+    pairs = [(a, b) for a in left for b in right]
+    assert len(pairs) == 500_000
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": gdf["cond"].astype(float)}, index=gdf.index)
+    torch.cuda.synchronize(); t0 = time.time()
+    memento.compute_2d_moments(adata, pairs)
+    torch.cuda.synchronize(); t1 = time.time()
+    np.random.seed(12)
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=B, num_cpus=8, verbose=0, resampling="bootstrap", approx=True)
+    torch.cuda.synchronize(); t2 = time.time()
+    print(f"\nC4 share: 500,000 pairs x 2 groups, {cells} cells, B={B}: compute_2d {t1 - t0:.1f} s, ht_2d {t2 - t1:.1f} s "
+          f"-> {len(pairs) / (t2 - t0):.0f} pair-tests/s")
+    groups = m["groups"]
+    ng = len(groups)
+    # ---- invariants over all 500k pairs ------------------------------------------------------------------------
+    corr = np.stack([m["2d_moments"][g]["corr"] for g in groups])                      # [group][pair]
+    fin = np.isfinite(corr)
+    assert fin.mean() > 0.99 and (np.abs(corr[fin]) <= 1).all()
+    ht = m["2d_ht"]
+    p, se, cf = ht["corr_asl"], ht["corr_se"], ht["corr_coef"]
+    ok = np.isfinite(p)
+    assert ok.mean() > 0.99 and ((p[ok] >= 0) & (p[ok] <= 1)).all() and (se[ok] > 0).all()
+    # two groups, intercept + binary treatment: the observed coefficient is the difference of the two true correlations
+    both = fin.all(axis=0) & (np.abs(corr) < 1).all(axis=0) & ok
+    tcol = trt["cond"].values
+    np.testing.assert_allclose(cf[both], (corr[tcol == 1][0] - corr[tcol == 0][0])[both], rtol=1e-9, atol=1e-12)
+    # labels are independent of the counts: p-values of this null are roughly uniform
+    assert 0.3 < np.median(p[ok]) < 0.7
+    # ---- oracle spot check: 20 (pair, group) chains of the last chunk, bins + every replicate correlation -------------------
+    true_corr = corr.T                                                                   # [pair][group]
+    with np.errstate(invalid="ignore"):
+        skip = np.isnan(true_corr) | (np.abs(true_corr) == 1)
+    live = ~skip.reshape(-1)
+    np.random.seed(12)
+    u = np.random.random(3 * int(live.sum()))                    # the hash uniforms ht_2d_moments drew (bootstrap.py:62, :65)
+    pos = np.cumsum(live) - 1
+    bs = st.last_bootstrap2d
+    lo, hi = st.last_chunk2d
+    yc = bs.yc
+    gid = st.group_id
+    sel = [np.flatnonzero(gid == j) for j in range(ng)]
+    asf = m["all_approx_size_factor"]
+    gq = [m["group_q"][g] for g in groups]
+    inv = np.empty(hi - lo, dtype=np.int64)
+    inv[bs.order] = np.arange(hi - lo)
+    name_to_col = {n: int(st.gene_idx[i]) for i, n in enumerate(names)}
+    picks = np.random.default_rng(0).choice(hi - lo, size=10, replace=False)
+    checked = 0
+    for pi in picks:
+        a, b = pairs[lo + pi]
+        cols = _dense_columns(csr, [name_to_col[a], name_to_col[b]], torch)
+        for j in range(ng):
+            flat = (lo + pi) * ng + j
+            if not live[flat]:
+                continue
+            k = pos[flat]
+            r, r0 = u[3 * k:3 * k + 2], u[3 * k + 2]
+            c1, c2, s_ = cols[sel[j], 0], cols[sel[j], 1], asf[sel[j]]
+            q = int(inv[pi]) * ng + j
+            _, _, e1, e2, mult = orc.unique_bins_2d(c1, c2, s_, r, r0)
+            bi, xi, xj, mu = bs.bins_of(q)
+            assert bs.K[q] == len(mult) and sorted(zip(xi.tolist(), xj.tolist(), mu.tolist())) == sorted(zip(e1.astype(int).tolist(), e2.astype(int).tolist(), mult.tolist()))
+            cv, v1, v2 = orc.bootstrap_2d(c1, c2, s_, gq[j], B, r, r0)
+            want = orc.corr_from_cov(cv, v1, v2)
+            got = engine.host(yc[q])
+            np.testing.assert_allclose(got[0], true_corr[lo + pi, j], rtol=1e-12)
+            np.testing.assert_allclose(got[1:], want, rtol=1e-9, atol=1e-12)
+            checked += 1
+    assert checked >= 15
+
+
+def test_c5_perturbseq_full_shape():
+    """configs[4]: 200k cells x 15k genes, 500 guide groups + 1 control (20 % of the cells), 5,000 bootstraps, every kept gene
+    against the shared control in one call."""
+    import torch
+
+    import bench
+    from oracle import memento_oracle as orc
+    from scrna_parameter_estimation_amd import AnnDataLite, engine, memento
+
+    cells, genes, n_guides, B = 200_000, 15_000, 500, 5_000
+    csr = bench.synth_device_csr(dict(cells=cells, genes=genes, density=0.05), 20250117 + 5, torch)
+    rng = np.random.default_rng(20250117 + 5)
+    is_ctrl = rng.random(cells) < 0.2
+    guide = np.where(is_ctrl, 0, 1 + rng.integers(0, n_guides, size=cells))
+    obs = pd.DataFrame({"guide": guide, "q": np.full(cells, 0.07)})
+    adata = AnnDataLite(sp.csr_matrix((cells, genes), dtype=np.float32), obs, pd.DataFrame(index=[f"g{i}" for i in range(genes)]))
+    memento.setup_memento(adata, q_column="q", device_csr=csr)
+    memento.create_groups(adata, label_columns=["guide"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+    m = adata.uns["memento"]
+    st = m["_hip"]
+    groups = m["groups"]
+    ng = len(groups)
+    assert ng == n_guides + 1
+    ctrl = [g for g in groups if g.split("^")[-1] == "0"][0]
+    ci = groups.index(ctrl)
+    G = len(st.gene_idx)
+    np.random.seed(0)
+    torch.cuda.synchronize(); t0 = time.time()
+    df = memento.ht_1d_vs_control(adata, control=ctrl, num_boot=B, num_cpus=8, approx=True)
+    torch.cuda.synchronize(); t1 = time.time()
+    print(f"\nC5: {G} genes x {n_guides} guides = {len(df)} tests, {cells} cells, B={B}: {t1 - t0:.1f} s -> {len(df) / (t1 - t0):.0f} tests/s")
+    assert len(df) == G * n_guides and G > 1500
+    # ---- invariants over all 1.3 M tests ----------------------------------------------------------------------------
+    mean = np.stack([m["1d_moments"][g][0] for g in groups])        # [group][gene]
+    rv = np.stack([m["1d_moments"][g][2] for g in groups])
+    others = [j for j in range(ng) if j != ci]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want_de = (np.log(mean[others]) - np.log(mean[ci])[None, :]).T.reshape(-1)          # gene-major x guide
+        want_dv = (np.log(rv[others]) - np.log(rv[ci])[None, :]).T.reshape(-1)
+    de, dv = df["de_coef"].values, df["dv_coef"].values
+    ok = np.isfinite(de)
+    assert ok.mean() > 0.95
+    np.testing.assert_allclose(de[ok], want_de[ok], rtol=1e-9, atol=1e-12)
+    okv = np.isfinite(dv) & np.isfinite(want_dv)
+    np.testing.assert_allclose(dv[okv], want_dv[okv], rtol=1e-8, atol=1e-11)
+    pv = df["de_pval"].values
+    assert ((pv[ok] >= 0) & (pv[ok] <= 1)).all() and (df["de_se"].values[ok] > 0).all()
+    assert 0.3 < np.median(pv[ok]) < 0.7                              # guide labels are independent of the counts
+    # ---- oracle spot check: ~20 (gene, guide) contrasts of the last gene chunk == the reference's two-group regression -----
+    bs = st.last_bootstrap
+    g0, g1 = st.last_chunk
+    Nc = np.array([m["group_cells"][k].shape[0] for k in groups], dtype=float)
+    r2 = np.random.default_rng(4)
+    checked = 0
+    for _ in range(40):
+        gi = int(r2.integers(g0, g1))
+        j = int(r2.choice(others))
+        rows = [(gi - g0) * ng + ci, (gi - g0) * ng + j]
+        ym, yv = engine.host(bs.ym[rows]), engine.host(bs.yv[rows])
+        if not (np.isfinite(ym[:, 0]).all() and np.isfinite(yv[:, 0]).all() and np.isfinite(ym[:, 1:]).all() and np.isfinite(yv[:, 1:]).all()):
+            continue
+        ref = orc.regress_1d(np.ones((2, 1)), np.array([[0.0], [1.0]]), ym, yv, Nc[[ci, j]], resampling="bootstrap", approx=True)
+        r = df.iloc[gi * n_guides + others.index(j)]
+        np.testing.assert_allclose([r.de_coef, r.de_se, r.de_pval, r.dv_coef, r.dv_se, r.dv_pval],
+                                   [ref[0][0], ref[1][0], ref[2][0], ref[3][0], ref[4][0], ref[5][0]], rtol=1e-7, atol=1e-12)
+        checked += 1
+        if checked == 20:
+            break
+    assert checked >= 15
+
+
+def test_vs_control_against_the_references_per_guide_loop(guide_loop):
+    """The reference's Perturb-seq pattern (subset to control + guide, create_groups, compute_1d_moments, ht_1d_moments, per
+    guide: analysis/sciplex/sciplex_dv.py:18-40 on the current API) run by the REAL reference (fixture guide_loop), against ONE
+    batched ht_1d_vs_control call.  Measured differences (printed): the mean coefficient is the same quantity (log-mean difference
+    with the global size factors) and must agree to 1e-8; standard errors and p-values differ only by Monte-Carlo error (different
+    size-factor binning on the subset, different bootstrap streams); the variability coefficient differs by the pooled
+    mean-variance fit (all groups here, the two-group subset there)."""
+    from scrna_parameter_estimation_amd import AnnDataLite, memento
+
+    g = guide_loop
+    X = sp.csr_matrix((g["in_data"].astype(np.float32), g["in_indices"], g["in_indptr"]), shape=tuple(g["in_shape"]))
+    obs = pd.DataFrame({"guide": g["in_guide"], "q": g["in_q"]}, index=[f"c{i}" for i in range(X.shape[0])])
+    adata = AnnDataLite(X, obs, pd.DataFrame(index=g["in_gene_names"].tolist()))
+    memento.setup_memento(adata, q_column="q")
+    np.testing.assert_allclose(adata.obs["memento_size_factor"].values, g["size_factor"], rtol=1e-12)
+    memento.create_groups(adata, label_columns=["guide"])
+    memento.compute_1d_moments(adata, min_perc_group=0.9)
+    m = adata.uns["memento"]
+    ctrl = [k for k in m["groups"] if k.split("^")[-1] == "0"][0]
+    np.random.seed(5)
+    df = memento.ht_1d_vs_control(adata, control=ctrl, num_boot=400, num_cpus=1, approx=True)
+    n_guides = int(g["n_guides"])
+    rel_de, ratio_se, diff_dv, n = [], [], [], 0
+    for gid in range(1, n_guides + 1):
+        sub = df[df["group"] == f"sg^{gid}"].set_index("gene")
+        genes = [x for x in g[f"g{gid}_genes"].tolist() if x in sub.index]
+        assert len(genes) > 0.8 * len(g[f"g{gid}_genes"])              # the per-guide loop filters genes on its two-group subset
+        idx = [g[f"g{gid}_genes"].tolist().index(x) for x in genes]
+        ours = sub.loc[genes]
+        ref_de, ref_se, ref_dv = g[f"g{gid}_mean_coef"][idx], g[f"g{gid}_mean_se"][idx], g[f"g{gid}_var_coef"][idx]
+        ok = np.isfinite(ref_de) & np.isfinite(ours["de_coef"].values)
+        np.testing.assert_allclose(ours["de_coef"].values[ok], ref_de[ok], rtol=1e-8, atol=1e-10)
+        rel_de.append(np.abs(ours["de_coef"].values[ok] - ref_de[ok]).max())
+        ratio_se.append(np.median(ours["de_se"].values[ok] / ref_se[ok]))
+        okv = ok & np.isfinite(ref_dv) & np.isfinite(ours["dv_coef"].values)
+        diff_dv.append(np.median(np.abs(ours["dv_coef"].values[okv] - ref_dv[okv])))
+        n += int(ok.sum())
+    print(f"\nper-guide loop vs batched: {n} (gene, guide) tests; max |de_coef diff| {max(rel_de):.2e}; median de_se ratio per guide "
+          f"{np.round(ratio_se, 3).tolist()}; median |dv_coef diff| per guide {np.round(diff_dv, 4).tolist()}")
+    assert all(0.85 < r < 1.15 for r in ratio_se)
+    assert max(diff_dv) < 0.1

@@ -1,5 +1,9 @@
 """Gene-sharded execution (one process per rank) gives the unsharded -- i.e. the real reference's --
-results: two ranks (gloo rendezvous, both on cuda:0) each hold all cells x half of the genes of the api_small fixture."""
+results: two ranks (gloo rendezvous, both on cuda:0) each hold all cells x half of the genes of the api_small fixture.
+Both ways in: the caller pre-slices X on the host, or (``shard=True``) hands the FULL matrix to every rank and the gene range
+is cut out on the device (mm_csr_colsplit).  ht_1d_moments ends with the gather: every rank holds the full result vectors in
+the unsharded run's gene order (the scatter-back of memento/main.py:399-412).  2D: pair blocks from dist.shard_pairs, results
+reassembled in the caller's pair order."""
 
 import os
 import subprocess
@@ -23,10 +27,14 @@ comm = Comm(device="cpu")
 g = dict(np.load(os.path.join(%(root)r, "tests", "golden", "api_small.npz"), allow_pickle=False))
 X = sp.csr_matrix((g["in_data"].astype(np.float32), g["in_indices"], g["in_indptr"]), shape=tuple(g["in_shape"]))
 lo, hi = shard_genes(X.shape[1], comm.rank, comm.world)
-Xs = sp.csr_matrix(X[:, lo:hi])
 obs = pd.DataFrame({"cond": g["in_cond"], "rep": g["in_rep"], "q": g["in_q"]}, index=[f"c{i}" for i in range(X.shape[0])])
-adata = AnnDataLite(Xs, obs, pd.DataFrame(index=g["in_gene_names"].tolist()[lo:hi]))
-memento.setup_memento(adata, q_column="q", comm=comm)
+if %(device_split)r:
+    adata = AnnDataLite(X, obs, pd.DataFrame(index=g["in_gene_names"].tolist()))       # the FULL matrix on every rank
+    memento.setup_memento(adata, q_column="q", comm=comm, shard=True)                   # device-side column split
+else:
+    Xs = sp.csr_matrix(X[:, lo:hi])
+    adata = AnnDataLite(Xs, obs, pd.DataFrame(index=g["in_gene_names"].tolist()[lo:hi]))
+    memento.setup_memento(adata, q_column="q", comm=comm)
 memento.create_groups(adata, label_columns=["cond", "rep"])
 memento.compute_1d_moments(adata, min_perc_group=0.7)
 m = adata.uns["memento"]
@@ -39,16 +47,39 @@ groups = m["groups"]
 np.savez(os.path.join(%(out)r, f"rank{comm.rank}.npz"), size_factor=adata.obs["memento_size_factor"].values,
          gene_list=np.array(m["gene_list"]), mean=np.stack([m["1d_moments"][k][0] for k in groups]),
          res_var=np.stack([m["1d_moments"][k][2] for k in groups]), mv=np.asarray(m["mv_regressor"]["all"]),
-         mean_coef=m["1d_ht"]["mean_coef"], var_coef=m["1d_ht"]["var_coef"])
+         mean_coef=m["1d_ht"]["mean_coef"], var_coef=m["1d_ht"]["var_coef"], ht_names=np.array(m["1d_ht"]["gene_names"]),
+         df_genes=np.array(memento.get_1d_ht_result(adata)["gene"].tolist()))
+# 2D on pair blocks (every rank needs all genes' columns: a second, unsharded state on the same device)
+from scrna_parameter_estimation_amd.dist import shard_pairs, gather_pair_results
+ad2 = AnnDataLite(X, obs.copy(), pd.DataFrame(index=g["in_gene_names"].tolist()))
+memento.setup_memento(ad2, q_column="q")
+memento.create_groups(ad2, label_columns=["cond", "rep"])
+memento.compute_1d_moments(ad2, min_perc_group=0.7)
+names = np.asarray(ad2.var.index)
+pairs = list(zip(names[g["pair_idx1"]].tolist(), names[g["pair_idx2"]].tolist()))
+mine, pos = shard_pairs(pairs, comm.rank, comm.world)
+memento.compute_2d_moments(ad2, mine)
+gdf2 = memento.get_groups(ad2)
+cov2 = pd.DataFrame(g["covariate"], index=gdf2.index, columns=["intercept"])
+trt2 = pd.DataFrame(g["treatment"], index=gdf2.index, columns=["cond"])
+np.random.seed(7 + comm.rank)
+memento.ht_2d_moments(ad2, covariate=cov2, treatment=trt2, num_boot=100, num_cpus=1, verbose=0, resampling="bootstrap", approx=True)
+m2 = ad2.uns["memento"]
+vals = {"corr_coef": m2["2d_ht"]["corr_coef"]}
+for gi, grp in enumerate(m2["groups"]):
+    vals[f"corr_{gi}"] = m2["2d_moments"][grp]["corr"]
+full = gather_pair_results(comm, pos, vals, len(pairs))
+np.savez(os.path.join(%(out)r, f"pairs_rank{comm.rank}.npz"), **full)
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-def test_two_gene_shards_equal_the_unsharded_reference(api_small, tmp_path):
+@pytest.mark.parametrize("device_split", [False, True])
+def test_two_gene_shards_equal_the_unsharded_reference(api_small, tmp_path, device_split):
     g = api_small
     script = tmp_path / "shard.py"
-    script.write_text(SCRIPT % {"root": ROOT, "out": str(tmp_path)})
+    script.write_text(SCRIPT % {"root": ROOT, "out": str(tmp_path), "device_split": device_split})
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", str(script)], capture_output=True, text=True, timeout=600, env=env)
@@ -60,6 +91,18 @@ def test_two_gene_shards_equal_the_unsharded_reference(api_small, tmp_path):
     assert list(parts[0]["gene_list"]) + list(parts[1]["gene_list"]) == list(g["gene_list"])
     np.testing.assert_allclose(np.concatenate([p["mean"] for p in parts], axis=1), g["mean"], rtol=1e-11)
     np.testing.assert_allclose(np.concatenate([p["res_var"] for p in parts], axis=1), g["res_var"], rtol=1e-7, equal_nan=True)
-    # observed coefficients do not depend on the bootstrap draws: identical to the reference's
-    np.testing.assert_allclose(np.concatenate([p["mean_coef"] for p in parts]), g["ht_mean_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
-    np.testing.assert_allclose(np.concatenate([p["var_coef"] for p in parts]), g["ht_var_coef"], rtol=1e-7, atol=1e-12, equal_nan=True)
+    # the gather: EVERY rank holds the full result vectors, in the unsharded gene order; observed coefficients do not depend on
+    # the bootstrap draws, so they are the real reference's
+    for p in parts:
+        assert list(p["ht_names"]) == list(g["gene_list"]) and list(p["df_genes"]) == list(g["gene_list"])
+        np.testing.assert_allclose(p["mean_coef"], g["ht_mean_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(p["var_coef"], g["ht_var_coef"], rtol=1e-7, atol=1e-12, equal_nan=True)
+    # 2D: pair blocks reassembled in the caller's order == the unsharded fixture (moments exactly; observed coefficients too)
+    pr = [dict(np.load(tmp_path / f"pairs_rank{k}.npz")) for k in range(2)]
+    for p in pr:
+        for gi in range(len(g["groups"])):
+            np.testing.assert_allclose(p[f"corr_{gi}"], g["corr2d"][gi], rtol=1e-8, equal_nan=True)
+        # ht_2d skips self pairs and fills duplicates within ONE call's list (main.py:473-482); a duplicate split over two ranks
+        # is tested on both, with the same observed coefficient
+        ok = np.isfinite(g["ht2_corr_coef"])
+        np.testing.assert_allclose(p["corr_coef"][ok], g["ht2_corr_coef"][ok], rtol=1e-8, atol=1e-12)

@@ -97,3 +97,82 @@ def test_replay_weights_edge_and_host_order_fallback(eng, monkeypatch):
             np.testing.assert_array_equal(wd[bs.pair_slot[p], :len(expr), :], w, err_msg=f"pair {p} caps {caps}")
         results.append(rm)
     np.testing.assert_array_equal(results[0], results[1])  # device-ordered and host-ordered operands give identical replicates
+
+
+def test_explicitly_stored_zeros_are_accepted(eng):
+    """A CSR with explicitly stored zeros (common after subsetting or arithmetic on adata.X; the reference accepts any scipy CSR,
+    main.py:44) gives the same count blocks and moments as its zero-free twin."""
+    X, gid, ng = _edge_matrix()
+    Z = X.tolil()
+    Z[0, 3] = 1.0
+    Z[5, 11] = 1.0
+    Z = Z.tocsr()
+    Z.data[(Z.indices == 3) | ((Z.indices == 11) & (np.arange(Z.nnz) < Z.indptr[6]) & (np.arange(Z.nnz) >= Z.indptr[5]))] = 0.0
+    keep = X[5, 11]
+    Z[5, 11] = keep if keep else 0.0
+    assert (Z.data == 0).any() and (Z != X).nnz == 0
+    sf = np.random.default_rng(1).lognormal(0, 0.4, size=X.shape[0])
+    a = eng.CountBlocks(eng.DeviceCSR(X), gid, ng).moments(1.0 / sf)
+    b = eng.CountBlocks(eng.DeviceCSR(Z), gid, ng).moments(1.0 / sf)
+    for u, v in zip(a, b):
+        np.testing.assert_allclose(u, v, rtol=1e-13, atol=0)
+
+
+def test_2d_host_ordering_fallback_equals_device_order(api_small, monkeypatch):
+    """A (pair, group) with more unique bins than the in-LDS sort holds is ordered on the host (engine.Bootstrap2D._order_on_host,
+    the same arithmetic as k_bins_order2d): forcing EVERY pair through that path gives bit-identical replicate correlations."""
+    import pandas as pd
+
+    from scrna_parameter_estimation_amd import AnnDataLite, engine, memento
+
+    g = api_small
+    X = sp.csr_matrix((g["in_data"].astype(np.float32), g["in_indices"], g["in_indptr"]), shape=tuple(g["in_shape"]))
+    obs = pd.DataFrame({"cond": g["in_cond"], "rep": g["in_rep"], "q": g["in_q"]}, index=[f"c{i}" for i in range(X.shape[0])])
+    adata = AnnDataLite(X, obs, pd.DataFrame(index=g["in_gene_names"].tolist()))
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    names = np.asarray(adata.var.index)
+    pairs = [(names[i], names[i + 1]) for i in range(0, 12, 2)]
+    memento.compute_2d_moments(adata, pairs)
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame(g["covariate"], index=gdf.index, columns=["intercept"])
+    trt = pd.DataFrame(g["treatment"], index=gdf.index, columns=["cond"])
+    rows = []
+    for cap in (engine.ORDER_BIG_CAP_2D, 0):
+        monkeypatch.setattr(engine, "ORDER_BIG_CAP_2D", cap)
+        if cap == 0:
+            monkeypatch.setattr(engine, "ORDER_SMALL_CAP", 0)
+        np.random.seed(4)
+        memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=64, num_cpus=1, verbose=0, resampling="bootstrap", approx=True)
+        rows.append(engine.host(adata.uns["memento"]["_hip"].last_bootstrap2d.yc).copy())
+    np.testing.assert_array_equal(rows[0], rows[1])
+
+
+def test_mean_filter_tie_follows_scipy_rounding(eng):
+    """sum / n == filter_mean_thresh exactly (189 counts in 2,700 cells = 0.07): the reference's scipy mean is
+    sum_c fl(x_c / n) in a specific order and lands a few ulp off the exact quotient; memento.main._plain_means reproduces it
+    (sequential for the CSR of all cells, first + pairwise(rest) for a group's CSC copy) -- compared here with scipy itself."""
+    from scrna_parameter_estimation_amd.memento.main import _plain_means
+
+    rng = np.random.default_rng(8)
+    n, G = 2700, 24
+    X = np.zeros((n, G))
+    for gcol in range(G):                      # every gene: exactly 189 counts, spread differently (1s, 2s, 3s) over the cells
+        left = 189
+        while left > 0:
+            v = min(left, int(rng.integers(1, 4)))
+            c = int(rng.integers(0, n))
+            if X[c, gcol] == 0:
+                X[c, gcol] = v
+                left -= v
+    Xs = sp.csr_matrix(X)
+    assert (np.asarray(Xs.sum(axis=0)).ravel() == 189).all()
+    blocks = eng.CountBlocks(eng.DeviceCSR(Xs.astype(np.float32)), np.zeros(n, dtype=np.int32), 1)
+    _, sumx, _ = blocks.moments(np.ones(n))
+    want_csr = np.asarray(Xs.mean(axis=0)).ravel()
+    want_csc = np.asarray(Xs.tocsc().mean(axis=0)).ravel()
+    assert len(set(want_csr.tolist())) > 1 or len(set(want_csc.tolist())) > 1      # the rounding really depends on the gene
+    np.testing.assert_array_equal(_plain_means(blocks, sumx, [n], 0.07, 'csr')[0], want_csr)
+    np.testing.assert_array_equal(_plain_means(blocks, sumx, [n], 0.07, 'csc')[0], want_csc)
+    np.testing.assert_array_equal(_plain_means(blocks, sumx, [n], 0.05, 'csc')[0], np.full(G, 189 / 2700))    # no tie: exact quotient
