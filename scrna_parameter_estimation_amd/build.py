@@ -20,6 +20,7 @@ SOURCES = [
     ("boot.hip", ["-ffp-contract=off"]),
     ("contract.hip", ["-ffp-contract=off"]),   # mirrors numpy's unfused weighted sums (degenerate resampled columns)
     ("pairs.hip", []),
+    ("simulate.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # experiment hook: extra -D flags for kernel tuning (e.g. MM_EXTRA_DEFS="-DK1_UNROLL=8 -DMM_ITEM_ROWS=32")

@@ -8,3 +8,4 @@
 from .main import (setup_memento, create_groups, compute_1d_moments, compute_2d_moments, ht_1d_moments,  # noqa: F401
                    ht_2d_moments, get_1d_moments, get_2d_moments, get_1d_ht_result, get_2d_ht_result, prepare_to_save,
                    get_corr_matrix, get_groups, ht_1d_vs_control)
+from . import simulate  # noqa: F401,E402  (reference: memento/main.py:23 imports memento.simulate as well)

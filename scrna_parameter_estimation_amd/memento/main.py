@@ -486,6 +486,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             rs['chains_refilled'] += int(refilled.sum())
             rs['genes'] += G
             rs['genes_refilled'] += int(refilled.reshape(G, ng).any(axis=1).sum())
+            rs['gene_refilled'][g0:g1] = refilled.reshape(G, ng).any(axis=1)
         else:
             def strict_pass():
                 """One sequential replay of the reference's global-stream consumption over all genes (speculate, then roll back to
@@ -621,7 +622,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         return out
 
     G_all = len(st.gene_idx)
-    st.refill_stats = dict(chains=0, chains_refilled=0, genes=0, genes_refilled=0)
+    st.refill_stats = dict(chains=0, chains_refilled=0, genes=0, genes_refilled=0, gene_refilled=np.zeros(G_all, dtype=bool))
     if max_rows is None:                       # replicate buffers sized to the free HBM (288 GB on MI355X)
         max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
     chunk = G_all if strict else max(1, int(max_rows) // max(1, ng))   # strict replay is sequential over all genes

@@ -184,3 +184,57 @@ def test_null_calibration(rng_mode):
     lam = np.median(chi2) / stats.chi2.ppf(0.5, 1)          # genomic inflation factor; the reference reports 0.9956
     assert 0.75 < lam < 1.3, lam
     assert stats.kstest(p, "uniform").pvalue > 1e-4
+
+
+def test_timed_mode_equals_strict_mode_on_genes_without_refills():
+    """bench.py times strict=False (invalid replicates refilled on the device); the reference-pinned mode is strict=True (the
+    reference's own _fill draws replayed from the global stream).  At configs[1] size (C2: 100k cells x 20k genes, 8 groups,
+    1,000 bootstraps, exact ASL incl. the host tail fits), on a 200-gene sample: for EVERY gene none of whose chains needed a
+    refill the two modes give bit-identical coefficients, standard errors and p-values; the others differ only by the refill
+    draws.  The refilled fraction is what bench.py reports as bootstrap.refilled_gene_frac."""
+    import pandas as pd
+    import scipy.sparse as sp
+    import torch
+
+    import bench
+    from scrna_parameter_estimation_amd import AnnDataLite, memento
+
+    cfg = dict(bench.CONFIGS["C2"])
+    N, G = cfg["cells"], cfg["genes"]
+    csr = bench.synth_device_csr(cfg, 20250117, torch)
+    rng = np.random.default_rng(20250117)
+    grp = rng.integers(0, cfg["n_cond"] * cfg["n_rep"], size=N)
+    obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
+    adata = AnnDataLite(sp.csr_matrix((N, G), dtype=np.float32), obs, pd.DataFrame(index=[f"g{i}" for i in range(G)]))
+    memento.setup_memento(adata, q_column="q", device_csr=csr)
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+    m = adata.uns["memento"]
+    st = m["_hip"]
+    kept = memento.main._var_names(adata)
+    assert len(kept) > 1000
+    sample = kept[:: len(kept) // 200][:200].tolist()
+    memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False, gene_list=sample)
+    assert len(st.gene_idx) == 200
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == 1).astype(float)}, index=gdf.index)
+    res = {}
+    for strict in (False, True):
+        np.random.seed(31)
+        memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=cfg["num_boot"], num_cpus=4, verbose=0,
+                              resampling="bootstrap", approx=False, strict=strict)
+        res[strict] = {k: m["1d_ht"][k].copy() for k in ("mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl")}
+        if not strict:
+            refilled = st.refill_stats["gene_refilled"].copy()
+    clean = ~refilled
+    print(f"\nC2 sample: {int(refilled.sum())} of 200 genes have at least one refilled replicate "
+          f"({st.refill_stats['chains_refilled']} of {st.refill_stats['chains']} chains)")
+    assert clean.sum() >= 100
+    for k in res[True]:
+        np.testing.assert_array_equal(res[False][k][clean], res[True][k][clean], err_msg=k)            # bit-identical
+        if k.endswith("coef"):
+            np.testing.assert_allclose(res[False][k], res[True][k], rtol=1e-12, equal_nan=True)       # observed values never depend on it
+    ok = refilled & np.isfinite(res[True]["var_se"])
+    if ok.any():
+        assert np.median(np.abs(res[False]["var_se"][ok] / res[True]["var_se"][ok] - 1)) < 0.05
