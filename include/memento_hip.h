@@ -148,6 +148,10 @@ int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t
  * (wave), {start, end (100 MHz wall clock), HW_ID, XCC_ID} into d_buf[tile*4 .. tile*4+3]; d_buf must hold 4*n_tiles
  * int64.  Pass NULL to switch it off.  Process-global; used by tools/replay_balance.py only. */
 int mm_debug_wave_clock(int64_t *d_buf);
+/* Measurement / test aid: exact != 0 makes the replay kernels (1D and 2D) evaluate every sampler search loop in numpy's fp64
+ * arithmetic; 0 (default) uses the guarded fp32 evaluation of those loops (csrc/npy_rng.h: same integer draws, the guard sends
+ * the ~0.1-0.5 % of draws that land near a decision threshold to the fp64 arithmetic).  Process-wide switch. */
+int mm_debug_replay_arith(int32_t exact);
 
 /* ---- K6+K7: replay bootstrap -- numpy Generator(PCG64).multinomial draw-for-draw + replicate moments
  * replaces bootstrap._bootstrap_1d  memento/bootstrap.py:97-110 and the tuple branch of

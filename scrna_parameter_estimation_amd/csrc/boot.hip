@@ -22,7 +22,7 @@
 #endif
 // MINW = waves per SIMD the register budget is set for: 2 when every tile is resident (<= 2048 tiles, the pairing order below
 // assumes two per SIMD), 3 in the many-tile regime where a third resident wave adds a little issue throughput.
-template <int MINW>
+template <int MINW, bool FAST>
 __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v, const double *__restrict__ a,
                                                        const double *__restrict__ b,
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
         if (k < K - 1) {
           w = 0;
           if (live) {
-            w = npyrng::binomial_pre<int32_t>(g, c_pk, c_lq, dn);
+            w = npyrng::binomial_pre<int32_t, FAST>(g, c_pk, c_lq, dn);
             dn -= w;
             if (dn <= 0) live = false;
           }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ 
     int64_t o = obase + (int64_t)k * 64;   // wave-uniform address: one broadcast load
     int32_t w;
     if (k < K - 1) {
-      w = dn > 0 ? npyrng::binomial_pre<int32_t>(g, pk_[o], lq_[o], dn) : 0;
+      w = dn > 0 ? npyrng::binomial_pre<int32_t, true>(g, pk_[o], lq_[o], dn) : 0;
       dn -= w;
     } else {
       w = dn > 0 ? dn : 0;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ 
 // covariance and the two variances (bootstrap.py:141-155, estimator.py:214-218, :171-174) are folded
 // into the correlation exactly as estimator._corr_from_cov does (:281-292: 5.0 sentinel where a variance
 // is <= 0, then clip to [-1, 1]).  Writes corr_b to out[row*ld + 1 + b].
-template <int MINW>
+template <int MINW, bool FAST>
 __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v1_, const double *__restrict__ v2_,
                                                        const double *__restrict__ a, const double *__restrict__ b,
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
         if (k < K - 1) {
           w = 0;
           if (live) {
-            w = npyrng::binomial_pre<int32_t>(g, c_pk, c_lq, dn);
+            w = npyrng::binomial_pre<int32_t, FAST>(g, c_pk, c_lq, dn);
             dn -= w;
             if (dn <= 0) live = false;
           }
@@ -338,11 +338,17 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
 }
 
 static int64_t *g_wave_clock = nullptr;  // set by mm_debug_wave_clock; nullptr = no profiling writes
+static int g_exact_arith = 0;            // set by mm_debug_replay_arith: 1 = numpy's fp64 arithmetic in every search loop (A/B timing, tests)
 
 extern "C" {
 
 int mm_debug_wave_clock(int64_t *d_buf) {
   g_wave_clock = d_buf;
+  return MM_OK;
+}
+
+int mm_debug_replay_arith(int32_t exact) {
+  g_exact_arith = exact ? 1 : 0;
   return MM_OK;
 }
 
@@ -357,7 +363,8 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
   MM_ARG(n_tiles < 2147483647LL);
   // 4 tiles per 256-thread workgroup: tiles t and t + 1024 (+-3) then meet on one SIMD, which engine.pair_tiles relies on
   // (one tile per workgroup was measured too: worse when everything is resident, a wash in the many-tile regime)
-  auto kern = n_tiles > 2048 ? k_boot1d_replay<3> : k_boot1d_replay<BOOT_MIN_WAVES>;
+  auto kern = n_tiles > 2048 ? (g_exact_arith ? k_boot1d_replay<3, false> : k_boot1d_replay<3, true>)
+                             : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false> : k_boot1d_replay<BOOT_MIN_WAVES, true>);
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock);
@@ -384,7 +391,8 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
   MM_ARG(d_pk && d_lq && d_v1 && d_v2 && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   MM_ARG(d_out_corr && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
-  auto kern = n_tiles > 2048 ? k_boot2d_replay<3> : k_boot2d_replay<BOOT_MIN_WAVES>;
+  auto kern = n_tiles > 2048 ? (g_exact_arith ? k_boot2d_replay<3, false> : k_boot2d_replay<3, true>)
+                             : (g_exact_arith ? k_boot2d_replay<BOOT_MIN_WAVES, false> : k_boot2d_replay<BOOT_MIN_WAVES, true>);
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, ld, d_out_corr);

@@ -27,6 +27,10 @@
 #pragma clang fp contract(off)
 #endif
 
+#ifndef NPY_NOTE_FALLBACK
+#define NPY_NOTE_FALLBACK(which)   // host tests count how often the guarded fast paths defer to the exact arithmetic
+#endif
+
 namespace npyrng {
 
 struct Pcg64 {
@@ -91,6 +95,9 @@ NPY_HD double btpe_stirling(double x, double x2) {
 
 // ---- binomial: BTPE for n*p > 30, p <= 0.5 ----------------------------------------------------
 template <typename Int>
+NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q);
+
+template <typename Int, bool FAST = false>
 NPY_HD Int binomial_btpe(Pcg64 &g, Int n, double p) {
   double r = p < 1.0 - p ? p : 1.0 - p;
   double q = 1.0 - r;
@@ -134,6 +141,12 @@ NPY_HD Int binomial_btpe(Pcg64 &g, Int n, double p) {
     Int k = y > m ? y - m : m - y;
     if (!((k > 20) && ((double)k < nrq / 2.0 - 1))) {
       // explicit evaluation of f(y)/f(m)
+      if (FAST) {
+        int dec = btpe_explicit_fast<Int>(v, n, m, y, r, q);
+        if (dec == 0) continue;
+        if (dec == 1) break;
+        NPY_NOTE_FALLBACK(1);
+      }
       double s = r / q;
       double aa = s * ((double)n + 1.0);
       double F = 1.0;
@@ -177,14 +190,15 @@ NPY_HD double binomial_lq(double pk) {
   return log(1.0 - p);
 }
 
+// ``U`` = the first uniform of this draw, already taken from the stream by the caller (the guarded fast path below looks at it
+// first); further uniforms are drawn only by numpy's restart rule.
 template <typename Int>
-NPY_HD Int binomial_inversion_pre(Pcg64 &g, Int n, double p, double lq) {
+NPY_HD Int binomial_inversion_pre(Pcg64 &g, Int n, double p, double lq, double U) {
   double q = 1.0 - p;
   double qn = exp((double)n * lq);
   Int bound = -1;  // computed lazily: np + 10*sqrt(np*q+1) >= 10, so X <= min(n, 9) can never exceed it
   Int X = 0;
   double px = qn;
-  double U = pcg64_next_double(g);
 #ifdef NPY_ABLATE_INV_LOOP  // timing experiments only: wrong results
   return (Int)(U > px);
 #endif
@@ -211,17 +225,100 @@ NPY_HD Int binomial_inversion_pre(Pcg64 &g, Int n, double p, double lq) {
   return X;
 }
 
-// binomial(pk, n) with lq = binomial_lq(pk) precomputed; identical draws to binomial(g, pk, n).
+// ---- guarded single-precision fast paths -------------------------------------------------------------------------------
+// The two data-dependent loops of the samplers -- the inversion search (one fp64 division per step) and BTPE's explicit
+// f(y)/f(m) product (one fp64 division per factor) -- only feed COMPARISONS (U > px, v > F).  They are evaluated here in
+// fp32 (2-cycle VALU ops, native v_rcp_f32 / v_exp_f32 instead of ~14-instruction fp64 division and ~70-instruction exp
+// sequences) and the result is used only when every comparison it decided is farther from its threshold than a guard that is
+// >= 6x the worst-case fp32 error; otherwise the caller runs numpy's exact fp64 arithmetic on the same uniforms.  So the integer
+// draw -- and with it the number of uniforms consumed -- is numpy's in every case; the guard only decides which arithmetic
+// computed it (about 1 draw in 1,000 falls back).  Host tests compare millions of draws with numpy (tests/test_npy_rng_host.py).
+#if defined(__HIP_DEVICE_COMPILE__)
+NPY_HD float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+NPY_HD float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+NPY_HD float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+NPY_HD float f_rcp(float x) { return 1.0f / x; }
+NPY_HD float f_exp(float x) { return exp2f(x * 1.44269504088896341f); }
+NPY_HD float f_sqrt(float x) { return sqrtf(x); }
+#endif
+
+#ifndef NPY_INV_GUARD
+#define NPY_INV_GUARD 1.5e-4f // absolute, on U - CDF.  fp32 error of exp + recurrence + running subtraction: worst-case bound 4e-5 for X <= 60, largest seen in 2e7 random draws 8e-6
+#endif
+#ifndef NPY_F_GUARD
+#define NPY_F_GUARD 2e-4f     // relative, on v vs f(y)/f(m): fp32 error of a product of <= 64 factors < 3e-5
+#endif
+
+// Inversion search in fp32.  Returns X >= 0 when every decision of the search is outside the guard, -1 otherwise.
+// Decisions of numpy's loop: U_x > px_x for x < X and U_X <= px_X, with U_{x+1} = U_x - px_x; the margins of the x < X
+// decisions are U_{x+1} >= U_X, so two checks at the end cover them all: U_X > G (for X > 0) and px_X - U_X > G.
 template <typename Int>
+NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
+  float nf = (float)n, pf = (float)p;
+  float qf = 1.0f - pf;                       // p <= 0.5
+  float s = pf * f_rcp(qf);
+  float qn = f_exp((float)((double)n * lq));  // n*lq >= -1.39 n p >= about -42 for n*p <= 30 (p <= 0.5): inside the fp32 range
+  float npf = nf * pf;
+  // numpy restarts when X exceeds bound = min(n, np + 10 sqrt(npq + 1)); stay strictly below it (and below 60: longer searches
+  // are ~6 sigma events for n*p <= 30 and go to the exact path)
+  float capf = npf + 10.0f * f_sqrt(npf * qf + 1.0f) - 1.5f;
+  capf = capf < nf ? capf : nf;
+  capf = capf < 60.0f ? capf : 60.0f;
+  int32_t cap = (int32_t)capf;
+  float Uf = (float)U, px = qn;
+  int32_t X = 0;
+  while (Uf > px) {
+    X++;
+    if (X > cap) return -1;
+    Uf -= px;
+    px = px * ((nf - (float)X + 1.0f) * s) * f_rcp((float)X);
+  }
+  bool ok = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);
+  return ok ? X : -1;
+}
+
+// BTPE's explicit evaluation of f(y)/f(m) against v, in fp32.  +1: v <= F (numpy breaks: accept), 0: v > F (numpy continues:
+// reject), -1: inside the guard or too many factors -> the caller evaluates numpy's fp64 product.
+template <typename Int>
+NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q) {
+  Int k = y > m ? y - m : m - y;
+  if (k > 64) return -1;
+  float s = (float)r * f_rcp((float)q);
+  float aa = s * ((float)n + 1.0f);
+  Int lo = m < y ? m : y;
+  float P = 1.0f;
+  for (Int i = lo + 1; i <= lo + k; i++) P *= (aa * f_rcp((float)i) - s);   // every factor is ~ (1 - r)/q +- small: no cancellation
+  float vf = (float)v;
+  // m < y: F = P;  m > y: F = 1/P (P > 0), compare v*P with 1
+  float a_ = m <= y ? vf : vf * P;
+  float b_ = m <= y ? P : 1.0f;
+  float d = a_ - b_;
+  float mag = fabsf(a_) > fabsf(b_) ? fabsf(a_) : fabsf(b_);
+  if (!(fabsf(d) > NPY_F_GUARD * mag)) return -1;
+  return d > 0.0f ? 0 : 1;
+}
+
+// binomial(pk, n) with lq = binomial_lq(pk) precomputed; identical draws to binomial(g, pk, n).  FAST selects the guarded
+// fp32 evaluation of the two search loops (same draws, fewer instructions); FAST = false is numpy's arithmetic throughout.
+template <typename Int, bool FAST = false>
 NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
   if (n == 0 || pk == 0.0) return 0;
   bool flip = !(pk <= 0.5);
   double p = flip ? 1.0 - pk : pk;
+  Int X;
+  if (p * (double)n <= 30.0) {
+    double U = pcg64_next_double(g);
+    int32_t xf = FAST ? binomial_inversion_fast<Int>(U, n, p, lq) : -1;
+    if (FAST && xf < 0) NPY_NOTE_FALLBACK(0);
+    X = xf >= 0 ? (Int)xf : binomial_inversion_pre<Int>(g, n, p, lq, U);
+  } else {
 #ifdef NPY_ABLATE_BTPE  // timing experiments only: wrong results
-  Int X = (p * (double)n <= 30.0) ? binomial_inversion_pre<Int>(g, n, p, lq) : (Int)((double)n * p);
+    X = (Int)((double)n * p);
 #else
-  Int X = (p * (double)n <= 30.0) ? binomial_inversion_pre<Int>(g, n, p, lq) : binomial_btpe<Int>(g, n, p);
+    X = binomial_btpe<Int, FAST>(g, n, p);
 #endif
+  }
   return flip ? n - X : X;
 }
 

@@ -1,5 +1,7 @@
 // Host build of the product header csrc/npy_rng.h so the numpy-replay algorithm can be checked
 // against numpy itself on a machine without a GPU (tests/test_npy_rng_host.py).
+static long g_fallbacks[2] = {0, 0};
+#define NPY_NOTE_FALLBACK(which) (g_fallbacks[which]++)
 #include "npy_rng.h"
 
 extern "C" {
@@ -55,5 +57,42 @@ void host_multinomial_pre(const uint64_t st[4], int64_t n, const double *pix, in
   }
   delete[] pk;
   delete[] lq;
+}
+
+// the guarded fp32 fast paths of the search loops (what the HIP replay kernels run by default): draws must still be numpy's
+void host_multinomial_fast(const uint64_t st[4], int64_t n, const double *pix, int d, int B, int64_t *out) {
+  npyrng::Pcg64 g{st[0], st[1], st[2], st[3]};
+  double *pk = new double[d], *lq = new double[d];
+  double rem = 1.0;
+  for (int j = 0; j < d - 1; j++) {
+    pk[j] = pix[j] / rem;
+    lq[j] = npyrng::binomial_lq(pk[j]);
+    rem -= pix[j];
+  }
+  for (int b = 0; b < B; b++) {
+    int64_t *mn = out + (int64_t)b * d;
+    int32_t dn32 = (int32_t)n;
+    for (int j = 0; j < d - 1; j++) {
+      mn[j] = npyrng::binomial_pre<int32_t, true>(g, pk[j], lq[j], dn32);
+      dn32 -= (int32_t)mn[j];
+      if (dn32 <= 0) break;
+    }
+    if (dn32 > 0) mn[d - 1] = dn32;
+  }
+  delete[] pk;
+  delete[] lq;
+}
+
+// count binomial draws through binomial_pre<.., true> with explicit (n, p) and return the two fallback counters
+void host_binomial_fast(const uint64_t st[4], double p, int64_t n, int count, int64_t *out) {
+  npyrng::Pcg64 g{st[0], st[1], st[2], st[3]};
+  double lq = npyrng::binomial_lq(p);
+  for (int i = 0; i < count; i++) out[i] = npyrng::binomial_pre<int32_t, true>(g, p, lq, (int32_t)n);
+}
+
+void host_fallback_counts(long out[2], int reset) {
+  out[0] = g_fallbacks[0];
+  out[1] = g_fallbacks[1];
+  if (reset) g_fallbacks[0] = g_fallbacks[1] = 0;
 }
 }

@@ -74,7 +74,7 @@ def test_multinomial_random_shapes(shim):
         pv = mult / mult.sum()
         B = 50
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
-        for fn in ("host_multinomial", "host_multinomial_pre"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast"):
             got = _multi(shim, 5, n, pv, B, fn)
             np.testing.assert_array_equal(got, ref, err_msg=f"{fn} trial {trial} d={d} n={n}")
 
@@ -83,6 +83,52 @@ def test_multinomial_golden_weights(shim, internals_small):
     it = internals_small
     for k in range(int(it["n_picks"])):
         mult = it[f"p{k}_counts"]
-        for fn in ("host_multinomial", "host_multinomial_pre"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast"):
             got = _multi(shim, 5, int(it[f"p{k}_n_obs"]), mult / mult.sum(), int(it["num_boot"]), fn)
             np.testing.assert_array_equal(got.T, it[f"p{k}_weights"])
+
+
+def _fallbacks(shim, reset=True):
+    out = (ctypes.c_long * 2)()
+    shim.host_fallback_counts(out, int(reset))
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize("n,p", [(20, 0.1), (50000, 0.9), (7, 0.5), (100000, 0.0002), (100000, 0.03), (300, 0.4), (12345, 0.5),
+                                 (1 << 30, 1e-9), (1 << 30, 2.5e-8), (3, 0.99), (50000, 1e-12), (48000, 6.2e-4), (60, 0.5), (61, 0.49),
+                                 (2000, 0.0149), (25, 0.3), (9, 0.05), (1000000, 2.9e-5)])
+def test_guarded_fast_binomial_matches_numpy(shim, n, p):
+    """binomial_pre<., FAST=true>: fp32 search loops behind a guard, exact fp64 fallback -- draws identical to numpy's."""
+    cnt = 20000
+    out = np.zeros(cnt, dtype=np.int64)
+    _fallbacks(shim)
+    shim.host_binomial_fast(pcg_state(5), ctypes.c_double(p), ctypes.c_int64(n), cnt, out.ctypes.data_as(ctypes.c_void_p))
+    ref = np.random.Generator(np.random.PCG64(5)).binomial(n, p, cnt)
+    np.testing.assert_array_equal(out, ref)
+    inv_fb, f_fb = _fallbacks(shim)
+    assert inv_fb + f_fb < 0.02 * cnt + 5, (inv_fb, f_fb)          # the fast path really is the common path
+
+
+def test_guarded_fast_multinomial_stress(shim):
+    """C3-like chains (48k-cell groups, 60-350 bins, scRNA-like multiplicities) through the guarded fast paths: > 4e6 binomial
+    draws, every weight equal to numpy's; the guards send about 1 draw in 1,000 to the exact arithmetic."""
+    rng = np.random.default_rng(11)
+    draws = 0
+    _fallbacks(shim)
+    for trial in range(50):
+        d = int(rng.integers(60, 350))
+        heavy = max(3, d // 3)
+        mult = np.concatenate([rng.integers(200, 9000, size=heavy // 3 + 1), rng.integers(20, 200, size=heavy),
+                               rng.integers(1, 20, size=d - heavy - heavy // 3 - 1)])
+        rng.shuffle(mult)
+        n = int(mult.sum())
+        pv = mult / mult.sum()
+        B = 500
+        ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
+        got = _multi(shim, 5, n, pv, B, "host_multinomial_fast")
+        np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial} d={d} n={n}")
+        draws += (d - 1) * B
+    inv_fb, f_fb = _fallbacks(shim)
+    assert draws > 4_000_000
+    print(f"\n{draws} draws: inversion fallbacks {inv_fb} ({inv_fb / draws:.2e}), explicit-product fallbacks {f_fb} ({f_fb / draws:.2e})")
+    assert inv_fb < 5e-3 * draws and f_fb < 5e-3 * draws
