@@ -243,6 +243,112 @@ __global__ __launch_bounds__(1024) void k_sell_scatter(const int64_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// K0, range-partitioned form (rows with ascending column indices -- the canonical CSR every scipy / device producer here
+// emits).  The scattered 4-byte stores of k_sell_scatter above re-open every 64-byte line of the block's 20 MB entry region up
+// to 16 times, and with ~17 blocks in flight per XCD those lines do not survive in the 4 MB L2: measured at BASELINE configs[2]
+// (profiles/r02_k1_traffic_C3.json) 18.7 GB written + 17 GB fetched for 2.4 GB of entries.  Here a workgroup owns (block, a
+// contiguous range of gene ids): in a sorted row its entries are ONE contiguous segment, its cursors and rank table are a few KB
+// of LDS, and the workgroups of one block are numbered onto ONE XCD a few blocks at a time, so the block's open lines (one or two
+// per 4 genes, < 1 MB) stay in that XCD's L2 until they are complete.
+//
+// Step 0: per row, where each gene range starts (R + 1 offsets relative to the row start), and the structural checks
+// (column indices inside [0, G), strictly ascending).  One wave per row, coalesced index reads, R - 1 ballots per 64 entries.
+__global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                    const int32_t *__restrict__ cell_order, int64_t n_sel, int32_t n_genes,
+                                                    int32_t n_ranges, uint32_t *__restrict__ rowsplit, int32_t *__restrict__ status) {
+  int lane = mm_lane();
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int bad = 0;
+  for (int64_t r = wave; r < n_sel; r += nwaves) {
+    int cell = cell_order[r];
+    int64_t s = indptr[cell], e = indptr[cell + 1];
+    // lane k (1 <= k < R) accumulates the number of entries with column < bound_k = k*G/R
+    uint32_t mine = 0;
+    int prev_last = -1;
+    for (int64_t i0 = s; i0 < e; i0 += 64) {
+      int64_t i = i0 + lane;
+      int g = i < e ? indices[i] : 0x7fffffff;
+      int gp = __shfl_up(g, 1, 64);
+      if (lane == 0) gp = prev_last;
+      if (i < e && (g < 0 || g >= n_genes || g <= gp)) bad = 1;
+      prev_last = __shfl(g, 63, 64);
+      for (int k = 1; k < n_ranges; k++) {
+        int bound = (int)(((int64_t)k * n_genes) / n_ranges);
+        uint64_t bal = __ballot(g < bound);
+        if (lane == k) mine += (uint32_t)__popcll(bal);
+      }
+    }
+    if (lane == 0) mine = 0;
+    if (lane == n_ranges) mine = (uint32_t)(e - s);
+    if (lane <= n_ranges) rowsplit[r * (n_ranges + 1) + lane] = mine;
+  }
+  if (bad) atomicOr(status, 2);
+}
+
+// Steps 1 and 3: one workgroup per (block, gene range).  SCATTER = false: nnz per (block, gene) of the range -> blk_cnt.
+// SCATTER = true: entries to their final place (same layout contract as k_sell_scatter), values validated.
+template <bool SCATTER>
+__global__ __launch_bounds__(1024) void k_sell_ranges(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      const float *__restrict__ data, const int32_t *__restrict__ cell_order,
+                                                      const int32_t *__restrict__ blk_cell0, int32_t n_blocks, int32_t n_genes,
+                                                      int32_t n_slices, int32_t n_ranges, const uint32_t *__restrict__ rowsplit,
+                                                      uint16_t *__restrict__ blk_cnt, const int32_t *__restrict__ rank,
+                                                      const int32_t *__restrict__ slice_ptr, const int64_t *__restrict__ blk_base,
+                                                      uint32_t *__restrict__ ent, int32_t *__restrict__ status) {
+  extern __shared__ uint32_t smem[];
+  // workgroup -> (block, range): the R workgroups of one block get ids that are equal mod 8, i.e. land on one XCD (speed only)
+  int x = blockIdx.x & 7, t = blockIdx.x >> 3;
+  int b = (t / n_ranges) * 8 + x, rg = t % n_ranges;
+  if (b >= n_blocks) return;
+  int g0 = (int)(((int64_t)rg * n_genes) / n_ranges), g1 = (int)(((int64_t)(rg + 1) * n_genes) / n_ranges);
+  int ngr = g1 - g0;
+  uint32_t *cur = smem;                                  // [ngr] entry cursors / counts of this range's genes
+  int32_t *rk = (int32_t *)(smem + ngr);                 // [ngr] slot of each gene (SCATTER)
+  int32_t *sptr = rk + (SCATTER ? ngr : 0);              // [n_slices] first row of each slice (SCATTER)
+  for (int i = threadIdx.x; i < ngr; i += blockDim.x) {
+    cur[i] = 0;
+    if (SCATTER) rk[i] = rank[(int64_t)b * n_genes + g0 + i];
+  }
+  if (SCATTER)
+    for (int i = threadIdx.x; i < n_slices; i += blockDim.x) sptr[i] = slice_ptr[(int64_t)b * (n_slices + 1) + i];
+  __syncthreads();
+  int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
+  int lane = mm_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int64_t base = SCATTER ? blk_base[b] : 0;
+  int bad = 0;
+  const int64_t ld = n_ranges + 1;
+  for (int r = c0 + wave; r < c1; r += nw) {
+    int cell = cell_order[r];
+    int64_t s = indptr[cell];
+    uint32_t a = rowsplit[r * ld + rg], z = rowsplit[r * ld + rg + 1];
+    uint32_t cell_local = (uint32_t)(r - c0);
+    for (int64_t i = s + a + lane; i < s + z; i += 64) {
+      int gl = indices[i] - g0;
+      if (!SCATTER) {
+        atomicAdd(&cur[gl], 1u);
+      } else {
+        float xf = data[i];
+        if (!(xf >= 1.0f && xf <= (float)MM_MAX_COUNT && xf == floorf(xf))) {  // counts: positive integers inside the 19-bit field
+          bad = 1;
+          xf = 1.0f;
+        }
+        uint32_t j = atomicAdd(&cur[gl], 1u);
+        int sl = rk[gl];
+        int64_t row = base + sptr[sl >> 6] + (j >> 2);
+        ent[row * 256 + (sl & 63) * 4 + (j & 3)] = cell_local | ((uint32_t)xf << MM_CELL_BITS);
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ngr; i += blockDim.x) blk_cnt[(int64_t)b * n_genes + g0 + i] = (uint16_t)cur[i];
+  } else if (bad) {
+    atomicOr(status, 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 extern "C" {
 
 int mm_csr_rowsum(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows,
@@ -321,6 +427,65 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
                      d_blk_cell0, n_genes, n_slices, d_rank, d_slice_ptr, d_blk_base, d_ent);
   MM_LAUNCH_CHECK();
   return MM_OK;
+}
+
+int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, int64_t n_sel, int32_t n_genes,
+                  int32_t n_ranges, uint32_t *d_rowsplit, int32_t *d_status, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_cell_order && d_rowsplit && d_status && n_sel >= 0 && n_genes > 0);
+  MM_ARG(n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
+  if (n_sel == 0) return MM_OK;
+  int64_t blocks = (n_sel + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_sell_split, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_cell_order, n_sel,
+                     n_genes, n_ranges, d_rowsplit, d_status);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+static int sell_ranges_launch(bool scatter, const int64_t *d_indptr, const int32_t *d_indices, const float *d_data,
+                              const int32_t *d_cell_order, const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes,
+                              int32_t n_ranges, const uint32_t *d_rowsplit, uint16_t *d_blk_cnt, const int32_t *d_rank,
+                              const int32_t *d_slice_ptr, const int64_t *d_blk_base, uint32_t *d_ent, int32_t *d_status, void *stream) {
+  int32_t n_slices = (n_genes + 63) / 64;
+  int32_t ngr_max = n_genes / n_ranges + 1;
+  size_t shm = scatter ? ((size_t)ngr_max * 8 + (size_t)n_slices * 4) : (size_t)ngr_max * 4;
+  MM_ARG(shm <= 150 * 1024);
+  int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
+  MM_ARG(grid < 2147483647LL);
+  if (scatter) {
+    MM_HIP(hipFuncSetAttribute((const void *)k_sell_ranges<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_sell_ranges<true>, dim3((unsigned)grid), dim3(1024), shm, (hipStream_t)stream, d_indptr, d_indices, d_data,
+                       d_cell_order, d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_blk_cnt, d_rank, d_slice_ptr,
+                       d_blk_base, d_ent, d_status);
+  } else {
+    MM_HIP(hipFuncSetAttribute((const void *)k_sell_ranges<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_sell_ranges<false>, dim3((unsigned)grid), dim3(1024), shm, (hipStream_t)stream, d_indptr, d_indices, d_data,
+                       d_cell_order, d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_blk_cnt, d_rank, d_slice_ptr,
+                       d_blk_base, d_ent, d_status);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
+                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, const uint32_t *d_rowsplit, uint16_t *d_blk_cnt,
+                         void *stream) {
+  MM_ARG(d_indptr && d_indices && d_cell_order && d_blk_cell0 && d_rowsplit && d_blk_cnt);
+  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_genes <= 65536 && n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
+  if (n_blocks == 0) return MM_OK;
+  return sell_ranges_launch(false, d_indptr, d_indices, nullptr, d_cell_order, d_blk_cell0, n_blocks, n_genes, n_ranges, d_rowsplit,
+                            d_blk_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int mm_sell_scatter_ranges(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
+                           const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges,
+                           const uint32_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,
+                           uint32_t *d_ent, int32_t *d_status, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_data && d_cell_order && d_blk_cell0 && d_rowsplit && d_rank && d_slice_ptr && d_blk_base && d_ent);
+  MM_ARG(d_status && n_blocks >= 0 && n_genes > 0 && n_genes <= 65536 && n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
+  if (n_blocks == 0) return MM_OK;
+  return sell_ranges_launch(true, d_indptr, d_indices, d_data, d_cell_order, d_blk_cell0, n_blocks, n_genes, n_ranges, d_rowsplit,
+                            nullptr, d_rank, d_slice_ptr, d_blk_base, d_ent, d_status, stream);
 }
 
 }  // extern "C"

@@ -6,7 +6,7 @@ include/memento_hip.h.  Nothing in this module has a CPU fallback.
 """
 
 import ctypes
-import os
+
 from ctypes import c_void_p
 
 import numpy as np
@@ -21,9 +21,9 @@ ORDER_BIG_CAP_2D = 4096
 # Lane packing of the replay kernel.  (a) tile widths: every tile gets the same budget K_max * (C0 + C1 * lanes), the budget
 # is set so that about PACK_WAVES tiles come out (2 per SIMD, never more than 2048: a third wave on a SIMD is a second round);
 # C0/C1/PACK_WAVES were tuned on the hardware together with the pairing order below (profiles/README.md).
-PACK_C0 = float(os.environ.get('MM_PACK_C0', 220))
-PACK_C1 = float(os.environ.get('MM_PACK_C1', 3))
-PACK_WAVES = int(os.environ.get('MM_PACK_WAVES', 2000))
+PACK_C0 = 220.0
+PACK_C1 = 3.0
+PACK_WAVES = 2000
 # (b) measured time of one bin step of a wave of L chains running as the OLDER wave of its SIMD, us (tools/replay_balance.py,
 # C3): used to rank tiles by length for the dispatch order (pair_tiles)
 _PACK_L = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 56, 64)
@@ -31,9 +31,10 @@ _PACK_US = (1.34, 1.91, 2.35, 2.60, 2.86, 3.13, 3.29, 3.51, 3.88, 4.18, 4.40, 4.
 PACK_COST = np.interp(np.arange(1, 65), _PACK_L, _PACK_US)
 # (c) many-chain regime (more tiles than resident wave slots): 2 x 1024 slots; a SIMD retires ~1.46 lone-wave-seconds of tile
 # time per second (older wave 1.0 + younger ~0.46); a tile may take at most PACK_TAIL of the work-bound run time
-PACK_MAX_RESIDENT = int(os.environ.get('MM_PACK_MAX_RESIDENT', 2048))
+PACK_MAX_RESIDENT = 2048
 PACK_RATE = 1024 * 1.46
-PACK_TAIL = float(os.environ.get('MM_PACK_TAIL', 0.5))
+PACK_TAIL = 0.5
+PACK_FORCE = ""          # tools only (tools/pack_sweep.py): "res" / "cap" forces one of the two packings
 PACK_LAST = {}          # diagnostics of the last pack_lanes decision (tools/)
 
 
@@ -204,10 +205,24 @@ class CountBlocks:
         self.d_grp_blk0 = dev(self.grp_blk0)
         blk_cnt = zeros((nb, G), torch.int16)
         status = zeros((1,), torch.int32)
-        call("mm_sell_count", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
-                  P(blk_cnt), P(status), s)
-        if int(status.item()) != 0:
-            raise ValueError(f"count matrix must hold positive integer counts <= {MAX_COUNT} with valid column indices")
+        bad_data = ValueError(f"count matrix must hold positive integer counts <= {MAX_COUNT} with valid column indices")
+        # Range-partitioned ingest (rows with ascending column indices: every canonical CSR): a workgroup owns (block, gene-id
+        # range), so a row contributes one contiguous segment and the block's open lines complete in one XCD's L2.  R ranges so
+        # that a (row, range) segment is about one wave wide.
+        n_sel = len(self.cell_order)
+        R = int(min(16, G, max(1, -(-int(csr.nnz) // (56 * max(1, csr.shape[0]))))))
+        rowsplit = empty((max(1, n_sel), R + 1), torch.int32)
+        call("mm_sell_split", P(csr.indptr), P(csr.indices), P(self.d_cell_order), n_sel, G, R, P(rowsplit), P(status), s)
+        self.ranged = (int(status.item()) & 2) == 0
+        if self.ranged:
+            call("mm_sell_count_ranges", P(csr.indptr), P(csr.indices), P(self.d_cell_order), P(self.d_blk_cell0), nb, G, R,
+                 P(rowsplit), P(blk_cnt), s)
+        else:       # unsorted rows (or column indices out of range: reported by the count kernel): the unpartitioned kernels
+            status.zero_()
+            call("mm_sell_count", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
+                 P(blk_cnt), P(status), s)
+            if int(status.item()) != 0:
+                raise bad_data
         self.rank = empty((nb, G), torch.int32)
         self.perm = empty((nb, ns * 64), torch.int32)
         self.slice_w = empty((nb, ns), torch.int32)
@@ -226,8 +241,15 @@ class CountBlocks:
         self.blk_base = dev(base[:-1])
         self.blk_item_base = dev(ibase[:-1])
         self.ent = zeros((max(1, self.total_rows) * 256,), torch.int32)
-        call("mm_sell_scatter", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
-                  P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), s)
+        if self.ranged:
+            call("mm_sell_scatter_ranges", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G, R,
+                 P(rowsplit), P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), P(status), s)
+            if int(status.item()) & 1:
+                raise bad_data
+        else:
+            call("mm_sell_scatter", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
+                 P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), s)
+        del rowsplit
         self.blk_cnt = host(blk_cnt, np.uint16)            # nnz per (block, gene), host copy [nb][G]
         self.nnz_sel = int(self.blk_cnt.astype(np.int64).sum())
         del blk_cnt
@@ -358,9 +380,8 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
     longest_resident = float((Ks * c[lanes - 1]).max())
     n_res = float((1.0 / lanes).sum())
     use_work_bound = n_res > PACK_MAX_RESIDENT or 1.35 * max(work(lanes_w), T) < longest_resident
-    force = os.environ.get("MM_PACK_FORCE", "")           # tuning hook: "res" / "cap"
-    if force:
-        use_work_bound = force == "cap" or n_res > PACK_MAX_RESIDENT
+    if PACK_FORCE:
+        use_work_bound = PACK_FORCE == "cap" or n_res > PACK_MAX_RESIDENT
     PACK_LAST.update(chains=n_act, tiles_resident=n_res, longest_resident=longest_resident, work_resident=work(lanes),
                      T_work_bound=T, work_work_bound=work(lanes_w), tiles_work_bound=float((1.0 / lanes_w).sum()),
                      chosen="work-bound" if use_work_bound else "resident")
@@ -369,7 +390,8 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
     return _tiles_from_lanes(lanes, n_act)
 
 
-PAIR_SLOTS = int(os.environ.get("MM_PAIR_SLOTS", 1024))      # SIMDs: tiles t and t + PAIR_SLOTS share one
+PAIR_SLOTS = 1024      # SIMDs: tiles t and t + PAIR_SLOTS share one
+PAIR_TILES = True      # tools only: False = plain longest-first dispatch order
 
 
 def pair_tiles(slot_of, n_tiles, K_of):
@@ -378,7 +400,7 @@ def pair_tiles(slot_of, n_tiles, K_of):
     out round-robin, so tile t and tile t + 1024 meet on one SIMD: put the 1024 longest tiles first, longest first, and
     behind them the next 1024 in ASCENDING length -- the longest tile then shares its SIMD with the shortest partner
     instead of one of its own size; anything beyond 2048 follows longest-first and refills slots as they free up."""
-    if os.environ.get("MM_PAIR_TILES", "1") == "0" or n_tiles <= 2:
+    if not PAIR_TILES or n_tiles <= 2:
         return slot_of
     tile = slot_of // 64
     lanes = np.bincount(tile, minlength=n_tiles)

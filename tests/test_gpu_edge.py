@@ -176,3 +176,34 @@ def test_mean_filter_tie_follows_scipy_rounding(eng):
     np.testing.assert_array_equal(_plain_means(blocks, sumx, [n], 0.07, 'csr')[0], want_csr)
     np.testing.assert_array_equal(_plain_means(blocks, sumx, [n], 0.07, 'csc')[0], want_csc)
     np.testing.assert_array_equal(_plain_means(blocks, sumx, [n], 0.05, 'csc')[0], np.full(G, 189 / 2700))    # no tie: exact quotient
+
+
+def test_unsorted_rows_take_the_unpartitioned_ingest(eng):
+    """The range-partitioned ingest needs ascending column indices inside a row; a device CSR whose rows are not sorted is
+    detected (mm_sell_split) and goes through the unpartitioned kernels -- same count blocks, same moments."""
+    import torch
+
+    X, gid, ng = _edge_matrix()
+    sf = np.random.default_rng(1).lognormal(0, 0.4, size=X.shape[0])
+    a = eng.CountBlocks(eng.DeviceCSR(X), gid, ng)
+    assert a.ranged
+    idx, dat, ptr = X.indices.copy(), X.data.copy(), X.indptr
+    rng = np.random.default_rng(3)
+    for r in range(X.shape[0]):                       # shuffle the entries of every row
+        p = rng.permutation(ptr[r + 1] - ptr[r]) + ptr[r]
+        idx[ptr[r]:ptr[r + 1]], dat[ptr[r]:ptr[r + 1]] = idx[p], dat[p]
+    csr = eng.DeviceCSR.from_device(torch.from_numpy(ptr.astype(np.int64)).cuda(), torch.from_numpy(idx.astype(np.int32)).cuda(),
+                                    torch.from_numpy(dat.astype(np.float32)).cuda(), X.shape)
+    b = eng.CountBlocks(csr, gid, ng)
+    assert not b.ranged
+    for u, v in zip(a.moments(1.0 / sf), b.moments(1.0 / sf)):
+        np.testing.assert_allclose(u, v, rtol=1e-13, atol=0)
+
+
+def test_invalid_counts_are_rejected(eng):
+    X, gid, ng = _edge_matrix()
+    for bad in (0.5, -1.0, 600000.0):
+        Y = X.copy()
+        Y.data[7] = bad
+        with pytest.raises(ValueError):
+            eng.CountBlocks(eng.DeviceCSR(Y) if bad != 600000.0 else eng.DeviceCSR(Y), gid, ng)

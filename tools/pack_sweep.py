@@ -1,0 +1,35 @@
+"""Sweep of the replay kernel's lane-packing constants (engine.PACK_C0 / PACK_C1 / PACK_WAVES) on one shape, in ONE process.
+These are module attributes the tools set directly; the product path reads no environment variable.
+usage: python tools/pack_sweep.py [config=C3] "c0,c1,waves" ["c0,c1,waves" ...]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pandas as pd, torch, scipy.sparse as sp
+import bench
+from scrna_parameter_estimation_amd import AnnDataLite, engine, memento, _lib
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+combos = [tuple(float(x) for x in a.split(",")) for a in sys.argv[2:]] or [(220, 3, 2000)]
+cfg = bench.CONFIGS[name]
+N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
+ng = cfg["n_cond"] * cfg["n_rep"]
+csr = bench.synth_device_csr(cfg, 20250117, torch)
+grp = np.random.default_rng(20250117).integers(0, ng, size=N)
+obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
+adata = AnnDataLite(sp.csr_matrix((N, G), dtype=np.float32), obs, pd.DataFrame(index=[f"g{i}" for i in range(G)]))
+memento.setup_memento(adata, q_column="q", device_csr=csr)
+memento.create_groups(adata, label_columns=["cond", "rep"])
+memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+m = adata.uns["memento"]; st = m["_hip"]
+gq = np.array([m["group_q"][g] for g in m["groups"]])
+bs = engine.Bootstrap1D(st.blocks, st.gene_idx, st.maxx, st.sf_bin, st.sf_table, gq, B)
+skip = ~(bs.K >= 2)
+r = np.random.default_rng(0).random((2, bs.n_pairs))
+bs.alloc_outputs(np.zeros(bs.n_pairs), np.zeros(bs.n_pairs))
+timer = ctypes.c_void_p(); _lib.call("mm_timer_create", ctypes.byref(timer)); s = engine._stream(); ms = ctypes.c_float()
+for c0, c1, waves in combos:
+    engine.PACK_C0, engine.PACK_C1, engine.PACK_WAVES = float(c0), float(c1), int(waves)
+    _lib.call("mm_timer_begin", timer, s)
+    bs.run(skip, r[0], r[1], m["mv_regressor"]["all"], fill_mode=1)
+    _lib.call("mm_timer_end", timer, s)
+    _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(ms))
+    print(f"{name} C0={c0:g} C1={c1:g} waves={int(waves)} -> tiles {bs.n_tiles} ({engine.PACK_LAST.get('chosen')})  bootstrap {ms.value:.0f} ms", flush=True)

@@ -63,6 +63,14 @@ def main():
         sel = (lanes >= lo) & (lanes < hi)
         if sel.any():
             print(f"  lanes [{lo},{hi}): {sel.sum():5d} waves, us per wave-step median {np.median(per_step[sel]):.2f} (p10 {np.quantile(per_step[sel], .1):.2f}, p90 {np.quantile(per_step[sel], .9):.2f}); steps median {np.median(steps[sel]):.0f}")
+    # step time of the OLDER wave of each SIMD (first half of the grid) by exact lane count: the table engine._PACK_US holds
+    older = np.arange(nt) < min(1024, nt // 2 + nt % 2)
+    tab = []
+    for L in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 56, 64):
+        sel = older & (lanes == L)
+        if sel.sum() >= 3:
+            tab.append((L, round(float(np.median(per_step[sel])), 2), int(sel.sum())))
+    print("older-wave us per step by lanes (L, us, n):", tab)
     np.savez_compressed(out, wc=wc, lanes=lanes, steps=steps, uid=uid, B=B)
 
 
