@@ -98,20 +98,22 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
                     const int32_t *d_slice_ptr, const int64_t *d_blk_base, uint32_t *d_ent, void *stream);
 /* Range-partitioned form of steps 1 and 3 for rows with strictly ascending column indices (canonical CSR): the path the
  * Python driver takes; mm_sell_count / mm_sell_scatter above remain for unsorted rows.  n_ranges (1..32) contiguous gene-id
- * ranges [k*G/R, (k+1)*G/R).  mm_sell_split: d_rowsplit[r][0..R] = offsets (relative to the row start) at which the ranges begin in
+ * ranges [k*G/R, (k+1)*G/R).  mm_sell_split: d_rowsplit[r][0..R] = absolute positions in d_indices / d_data at which the ranges begin in
  * selected row r (block order, n_sel rows); d_status |= 2 if some row is not strictly ascending or has a column outside [0, G).
  * mm_sell_count_ranges fills d_blk_cnt like mm_sell_count (without the value check); mm_sell_scatter_ranges places the entries
- * like mm_sell_scatter and validates the values (d_status |= 1: not a positive integer count <= MM_MAX_COUNT).
- * One workgroup per (block, range); the workgroups of a block share an XCD so that the block's open 64-byte lines complete in L2
- * (measured: the unpartitioned scatter writes 7.8x and fetches 3.6x its algorithmic bytes, profiles/r02_k1_traffic_C3.json). */
+ * in the layout of mm_sell_scatter and validates the values (d_status |= 1: not a positive integer count <= MM_MAX_COUNT).
+ * One workgroup per (block, range).  The scatter parks entries in LDS and stores only complete 16-byte groups (4 consecutive
+ * entries of one gene): stores are written through on this chip, a lone 4-byte store costs ~26 B of HBM write traffic (measured:
+ * the unpartitioned scatter writes 7.8x its algorithmic bytes, profiles/r02_k1_traffic_C3.json).  Each gene is owned by one wave
+ * that walks the block's rows in order, so a gene's entries are in ascending cell order: the ingest is DETERMINISTIC. */
 int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, int64_t n_sel, int32_t n_genes,
-                  int32_t n_ranges, uint32_t *d_rowsplit /* [n_sel][n_ranges+1] */, int32_t *d_status, void *stream);
+                  int32_t n_ranges, int64_t *d_rowsplit /* [n_sel][n_ranges+1] */, int32_t *d_status, void *stream);
 int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
-                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, const uint32_t *d_rowsplit, uint16_t *d_blk_cnt,
+                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, const int64_t *d_rowsplit, uint16_t *d_blk_cnt,
                          void *stream);
 int mm_sell_scatter_ranges(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
                            const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges,
-                           const uint32_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,
+                           const int64_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,
                            uint32_t *d_ent, int32_t *d_status, void *stream);
 
 /* ---- K1+K2: per-(item, gene slot) moment sums from the count blocks  (the HBM-roofline kernel) ---

@@ -247,15 +247,17 @@ __global__ __launch_bounds__(1024) void k_sell_scatter(const int64_t *__restrict
 // emits).  The scattered 4-byte stores of k_sell_scatter above re-open every 64-byte line of the block's 20 MB entry region up
 // to 16 times, and with ~17 blocks in flight per XCD those lines do not survive in the 4 MB L2: measured at BASELINE configs[2]
 // (profiles/r02_k1_traffic_C3.json) 18.7 GB written + 17 GB fetched for 2.4 GB of entries.  Here a workgroup owns (block, a
-// contiguous range of gene ids): in a sorted row its entries are ONE contiguous segment, its cursors and rank table are a few KB
-// of LDS, and the workgroups of one block are numbered onto ONE XCD a few blocks at a time, so the block's open lines (one or two
-// per 4 genes, < 1 MB) stay in that XCD's L2 until they are complete.
+// contiguous range of gene ids): in a sorted row its entries are ONE contiguous segment, and its per-gene state is a few KB of LDS
+// -- small enough to park every gene's open 16-byte group there (k_sell_scatter_quads) instead of storing entry by entry.
 //
-// Step 0: per row, where each gene range starts (R + 1 offsets relative to the row start), and the structural checks
+// Step 0: per row, where each gene range starts (R + 1 absolute positions in indices / data), and the structural checks
 // (column indices inside [0, G), strictly ascending).  One wave per row, coalesced index reads, R - 1 ballots per 64 entries.
 __global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                     const int32_t *__restrict__ cell_order, int64_t n_sel, int32_t n_genes,
-                                                    int32_t n_ranges, uint32_t *__restrict__ rowsplit, int32_t *__restrict__ status) {
+                                                    int32_t n_ranges, int64_t *__restrict__ rowsplit, int32_t *__restrict__ status) {
+  __shared__ int32_t bnd[33];                       // bnd[k] = first gene id of range k
+  if (threadIdx.x <= n_ranges) bnd[threadIdx.x] = (int32_t)(((int64_t)threadIdx.x * n_genes) / n_ranges);
+  __syncthreads();
   int lane = mm_lane();
   int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ 
   for (int64_t r = wave; r < n_sel; r += nwaves) {
     int cell = cell_order[r];
     int64_t s = indptr[cell], e = indptr[cell + 1];
-    // lane k (1 <= k < R) accumulates the number of entries with column < bound_k = k*G/R
+    // lane k (1 <= k < R) accumulates the number of entries with column < bnd[k]
     uint32_t mine = 0;
     int prev_last = -1;
     for (int64_t i0 = s; i0 < e; i0 += 64) {
@@ -274,28 +276,21 @@ __global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ 
       if (i < e && (g < 0 || g >= n_genes || g <= gp)) bad = 1;
       prev_last = __shfl(g, 63, 64);
       for (int k = 1; k < n_ranges; k++) {
-        int bound = (int)(((int64_t)k * n_genes) / n_ranges);
-        uint64_t bal = __ballot(g < bound);
+        uint64_t bal = __ballot(g < bnd[k]);        // wave-uniform bound (LDS broadcast), one s_bcnt1 per range
         if (lane == k) mine += (uint32_t)__popcll(bal);
       }
     }
     if (lane == 0) mine = 0;
     if (lane == n_ranges) mine = (uint32_t)(e - s);
-    if (lane <= n_ranges) rowsplit[r * (n_ranges + 1) + lane] = mine;
+    if (lane <= n_ranges) rowsplit[r * (n_ranges + 1) + lane] = s + (int64_t)mine;   // ABSOLUTE position in indices / data
   }
   if (bad) atomicOr(status, 2);
 }
 
-// Steps 1 and 3: one workgroup per (block, gene range).  SCATTER = false: nnz per (block, gene) of the range -> blk_cnt.
-// SCATTER = true: entries to their final place (same layout contract as k_sell_scatter), values validated.
-template <bool SCATTER>
-__global__ __launch_bounds__(1024) void k_sell_ranges(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                      const float *__restrict__ data, const int32_t *__restrict__ cell_order,
-                                                      const int32_t *__restrict__ blk_cell0, int32_t n_blocks, int32_t n_genes,
-                                                      int32_t n_slices, int32_t n_ranges, const uint32_t *__restrict__ rowsplit,
-                                                      uint16_t *__restrict__ blk_cnt, const int32_t *__restrict__ rank,
-                                                      const int32_t *__restrict__ slice_ptr, const int64_t *__restrict__ blk_base,
-                                                      uint32_t *__restrict__ ent, int32_t *__restrict__ status) {
+// Step 1: nnz per (block, gene).  One workgroup per (block, gene range); LDS counters of the range's genes only.
+__global__ __launch_bounds__(1024) void k_sell_count_ranges(const int32_t *__restrict__ indices, const int32_t *__restrict__ blk_cell0,
+                                                            int32_t n_blocks, int32_t n_genes, int32_t n_ranges,
+                                                            const int64_t *__restrict__ rowsplit, uint16_t *__restrict__ blk_cnt) {
   extern __shared__ uint32_t smem[];
   // workgroup -> (block, range): the R workgroups of one block get ids that are equal mod 8, i.e. land on one XCD (speed only)
   int x = blockIdx.x & 7, t = blockIdx.x >> 3;
@@ -303,49 +298,146 @@ __global__ __launch_bounds__(1024) void k_sell_ranges(const int64_t *__restrict_
   if (b >= n_blocks) return;
   int g0 = (int)(((int64_t)rg * n_genes) / n_ranges), g1 = (int)(((int64_t)(rg + 1) * n_genes) / n_ranges);
   int ngr = g1 - g0;
-  uint32_t *cur = smem;                                  // [ngr] entry cursors / counts of this range's genes
-  int32_t *rk = (int32_t *)(smem + ngr);                 // [ngr] slot of each gene (SCATTER)
-  int32_t *sptr = rk + (SCATTER ? ngr : 0);              // [n_slices] first row of each slice (SCATTER)
-  for (int i = threadIdx.x; i < ngr; i += blockDim.x) {
-    cur[i] = 0;
-    if (SCATTER) rk[i] = rank[(int64_t)b * n_genes + g0 + i];
-  }
-  if (SCATTER)
-    for (int i = threadIdx.x; i < n_slices; i += blockDim.x) sptr[i] = slice_ptr[(int64_t)b * (n_slices + 1) + i];
+  uint32_t *cur = smem;                                  // [ngr] counts of this range's genes
+  for (int i = threadIdx.x; i < ngr; i += blockDim.x) cur[i] = 0;
   __syncthreads();
   int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
   int lane = mm_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  int64_t base = SCATTER ? blk_base[b] : 0;
-  int bad = 0;
   const int64_t ld = n_ranges + 1;
-  for (int r = c0 + wave; r < c1; r += nw) {
-    int cell = cell_order[r];
-    int64_t s = indptr[cell];
-    uint32_t a = rowsplit[r * ld + rg], z = rowsplit[r * ld + rg + 1];
-    uint32_t cell_local = (uint32_t)(r - c0);
-    for (int64_t i = s + a + lane; i < s + z; i += 64) {
-      int gl = indices[i] - g0;
-      if (!SCATTER) {
-        atomicAdd(&cur[gl], 1u);
-      } else {
-        float xf = data[i];
-        if (!(xf >= 1.0f && xf <= (float)MM_MAX_COUNT && xf == floorf(xf))) {  // counts: positive integers inside the 19-bit field
-          bad = 1;
-          xf = 1.0f;
-        }
-        uint32_t j = atomicAdd(&cur[gl], 1u);
-        int sl = rk[gl];
-        int64_t row = base + sptr[sl >> 6] + (j >> 2);
-        ent[row * 256 + (sl & 63) * 4 + (j & 3)] = cell_local | ((uint32_t)xf << MM_CELL_BITS);
+  // one row segment per wave iteration; the NEXT row's segment bounds are fetched while the current one is processed
+  int r = c0 + wave;
+  int64_t a = 0, z = 0;
+  if (r < c1) {
+    a = rowsplit[r * ld + rg];
+    z = rowsplit[r * ld + rg + 1];
+  }
+  for (; r < c1; r += nw) {
+    int rn = r + nw;
+    int64_t an = 0, zn = 0;
+    if (rn < c1) {
+      an = rowsplit[rn * ld + rg];
+      zn = rowsplit[rn * ld + rg + 1];
+    }
+    for (int64_t i = a + lane; i < z; i += 64) atomicAdd(&cur[indices[i] - g0], 1u);
+    a = an;
+    z = zn;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ngr; i += blockDim.x) blk_cnt[(int64_t)b * n_genes + g0 + i] = (uint16_t)cur[i];
+}
+
+// Step 3, deterministic and write-combined.  Measured on this chip (profiles/README.md, round 2): a 4-byte store to a line that
+// is not being written by the same wave instruction costs ~26 B of HBM write traffic -- stores are written through, L2 does not
+// merge them over time -- so the per-entry scatter above writes 15.9 GB for 2.4 GB of entries even with XCD-local workgroups.
+// Here an entry is first parked in LDS and only complete 16-byte groups (the 4 consecutive entries of one gene = one lane's
+// dwordx4 of a slice row) go to HBM.  To make that race-free WITHOUT atomics a gene belongs to exactly one WAVE: the workgroup owns
+// (block, gene range) as before and wave w of it owns the w-th quarter of that range; every wave walks ALL rows of the block in
+// order, loads the row's range segment (one coalesced load, shared through L1 by the 4 waves) and keeps the lanes whose gene is
+// its own.  Entries of one row have distinct genes, so the lanes of an iteration never collide, and a gene's entries arrive in
+// cell order: the entry order inside a gene is now DETERMINISTIC (ascending cell), as is every fp64 sum K1 forms from it.
+#define RS_WAVES 4
+__global__ __launch_bounds__(64 * RS_WAVES) void k_sell_scatter_quads(const int32_t *__restrict__ indices, const float *__restrict__ data,
+                                                                       const int32_t *__restrict__ blk_cell0, int32_t n_blocks,
+                                                                       int32_t n_genes, int32_t n_slices, int32_t n_ranges,
+                                                                       const int64_t *__restrict__ rowsplit, const int32_t *__restrict__ rank,
+                                                                       const int32_t *__restrict__ slice_ptr, const int64_t *__restrict__ blk_base,
+                                                                       uint32_t *__restrict__ ent, int32_t *__restrict__ status) {
+  extern __shared__ u32x4 smem_q[];                      // 16-byte aligned dynamic LDS (the group buffers are read as dwordx4)
+  uint32_t *smem = (uint32_t *)smem_q;
+  int x = blockIdx.x & 7, t = blockIdx.x >> 3;
+  int b = (t / n_ranges) * 8 + x, rg = t % n_ranges;
+  if (b >= n_blocks) return;
+  int g0 = (int)(((int64_t)rg * n_genes) / n_ranges), g1 = (int)(((int64_t)(rg + 1) * n_genes) / n_ranges);
+  int ngr = g1 - g0;
+  uint32_t *stage = smem;                                // [ngr][4] the open 16-byte group of every gene
+  uint32_t *cur = smem + (size_t)ngr * 4;                // [ngr] entries seen so far
+  int64_t *dst = (int64_t *)(cur + ngr + (ngr & 1));     // [ngr] ent index of the gene's entry 0: (base + sptr[slice])*256 + lane*4
+  for (int i = threadIdx.x; i < ngr; i += blockDim.x) {
+    cur[i] = 0;
+    int sl = rank[(int64_t)b * n_genes + g0 + i];
+    dst[i] = (blk_base[b] + slice_ptr[(int64_t)b * (n_slices + 1) + (sl >> 6)]) * 256 + (sl & 63) * 4;
+  }
+  __syncthreads();
+  int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
+  int lane = mm_lane(), wave = threadIdx.x >> 6;
+  int lo = (int)(((int64_t)wave * ngr) / RS_WAVES), hi = (int)(((int64_t)(wave + 1) * ngr) / RS_WAVES);   // this wave's genes
+  const int64_t ld = n_ranges + 1;
+  int bad = 0;
+  // A wave walks the rows strictly in order, so its latency per row is what bounds the kernel: the segment bounds and the first
+  // 64 column indices of the next RS_AHEAD rows are kept in flight (software pipeline in registers).
+#define RS_AHEAD 4
+  int64_t ca[RS_AHEAD], cz[RS_AHEAD], na[RS_AHEAD], nz[RS_AHEAD];
+  int cg[RS_AHEAD];
+  float cd[RS_AHEAD];
+  auto load_bounds = [&](int r0, int64_t *pa, int64_t *pz) {
+#pragma unroll
+    for (int u = 0; u < RS_AHEAD; u++) {
+      int r = r0 + u;
+      pa[u] = pz[u] = 0;
+      if (r < c1) {
+        pa[u] = rowsplit[(int64_t)r * ld + rg];
+        pz[u] = rowsplit[(int64_t)r * ld + rg + 1];
       }
     }
+  };
+  load_bounds(c0, ca, cz);
+#pragma unroll
+  for (int u = 0; u < RS_AHEAD; u++) {
+    bool in = ca[u] + lane < cz[u];
+    cg[u] = in ? indices[ca[u] + lane] : 0;
+    cd[u] = in ? data[ca[u] + lane] : 1.0f;
   }
-  if (!SCATTER) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < ngr; i += blockDim.x) blk_cnt[(int64_t)b * n_genes + g0 + i] = (uint16_t)cur[i];
-  } else if (bad) {
-    atomicOr(status, 1);
+  load_bounds(c0 + RS_AHEAD, na, nz);
+  for (int r0 = c0; r0 < c1; r0 += RS_AHEAD) {
+    // issued first, consumed in the NEXT pass: the next group's column indices and the bounds of the group after it
+    int ng[RS_AHEAD];
+    float nd[RS_AHEAD];
+    int64_t fa[RS_AHEAD], fz[RS_AHEAD];
+#pragma unroll
+    for (int u = 0; u < RS_AHEAD; u++) {
+      bool in = na[u] + lane < nz[u];
+      ng[u] = in ? indices[na[u] + lane] : 0;
+      nd[u] = in ? data[na[u] + lane] : 1.0f;      // all 64 lanes (the 4 waves share the lines through L1): no dependent load later
+    }
+    load_bounds(r0 + 2 * RS_AHEAD, fa, fz);
+#pragma unroll
+    for (int u = 0; u < RS_AHEAD; u++) {
+      int r = r0 + u;
+      if (r < c1) {
+        uint32_t cell_local = (uint32_t)(r - c0);
+        int64_t a = ca[u], z = cz[u];
+        for (int64_t i = a + lane; i < z; i += 64) {
+          bool first = i < a + 64;
+          int gl = (first ? cg[u] : indices[i]) - g0;
+          if (gl >= lo && gl < hi) {
+            float xf = first ? cd[u] : data[i];
+            if (!(xf >= 1.0f && xf <= (float)MM_MAX_COUNT && xf == floorf(xf))) {  // counts: positive integers inside the 19-bit field
+              bad = 1;
+              xf = 1.0f;
+            }
+            uint32_t j = cur[gl];
+            cur[gl] = j + 1;
+            stage[gl * 4 + (j & 3)] = cell_local | ((uint32_t)xf << MM_CELL_BITS);
+            if ((j & 3) == 3) {                            // the group is complete: one 16-byte store
+              u32x4 q = *(const u32x4 *)(stage + gl * 4);
+              *(u32x4 *)(ent + dst[gl] + (int64_t)(j >> 2) * 256) = q;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RS_AHEAD; u++) {
+      ca[u] = na[u]; cz[u] = nz[u]; cg[u] = ng[u]; cd[u] = nd[u];
+      na[u] = fa[u]; nz[u] = fz[u];
+    }
   }
+  // leftovers: the last, incomplete group of every gene of this wave (<= 3 entries; the rest of the group stays zero = padding)
+  for (int gl = lo + lane; gl < hi; gl += 64) {
+    uint32_t n = cur[gl];
+    for (uint32_t k = n & ~3u; k < n; k++) ent[dst[gl] + (int64_t)(k >> 2) * 256 + (k & 3)] = stage[gl * 4 + (k & 3)];
+  }
+  if (bad) atomicOr(status, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,7 +522,7 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
 }
 
 int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, int64_t n_sel, int32_t n_genes,
-                  int32_t n_ranges, uint32_t *d_rowsplit, int32_t *d_status, void *stream) {
+                  int32_t n_ranges, int64_t *d_rowsplit, int32_t *d_status, void *stream) {
   MM_ARG(d_indptr && d_indices && d_cell_order && d_rowsplit && d_status && n_sel >= 0 && n_genes > 0);
   MM_ARG(n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
   if (n_sel == 0) return MM_OK;
@@ -442,50 +534,45 @@ int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32
   return MM_OK;
 }
 
-static int sell_ranges_launch(bool scatter, const int64_t *d_indptr, const int32_t *d_indices, const float *d_data,
-                              const int32_t *d_cell_order, const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes,
-                              int32_t n_ranges, const uint32_t *d_rowsplit, uint16_t *d_blk_cnt, const int32_t *d_rank,
-                              const int32_t *d_slice_ptr, const int64_t *d_blk_base, uint32_t *d_ent, int32_t *d_status, void *stream) {
-  int32_t n_slices = (n_genes + 63) / 64;
-  int32_t ngr_max = n_genes / n_ranges + 1;
-  size_t shm = scatter ? ((size_t)ngr_max * 8 + (size_t)n_slices * 4) : (size_t)ngr_max * 4;
+int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
+                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, const int64_t *d_rowsplit, uint16_t *d_blk_cnt,
+                         void *stream) {
+  (void)d_indptr;
+  (void)d_cell_order;   // the row positions come from d_rowsplit; kept in the signature next to mm_sell_count's
+  MM_ARG(d_indices && d_blk_cell0 && d_rowsplit && d_blk_cnt);
+  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_genes <= 65536 && n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
+  if (n_blocks == 0) return MM_OK;
+  size_t shm = (size_t)(n_genes / n_ranges + 1) * 4;
   MM_ARG(shm <= 150 * 1024);
   int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
   MM_ARG(grid < 2147483647LL);
-  if (scatter) {
-    MM_HIP(hipFuncSetAttribute((const void *)k_sell_ranges<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_sell_ranges<true>, dim3((unsigned)grid), dim3(1024), shm, (hipStream_t)stream, d_indptr, d_indices, d_data,
-                       d_cell_order, d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_blk_cnt, d_rank, d_slice_ptr,
-                       d_blk_base, d_ent, d_status);
-  } else {
-    MM_HIP(hipFuncSetAttribute((const void *)k_sell_ranges<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_sell_ranges<false>, dim3((unsigned)grid), dim3(1024), shm, (hipStream_t)stream, d_indptr, d_indices, d_data,
-                       d_cell_order, d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_blk_cnt, d_rank, d_slice_ptr,
-                       d_blk_base, d_ent, d_status);
-  }
+  MM_HIP(hipFuncSetAttribute((const void *)k_sell_count_ranges, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_sell_count_ranges, dim3((unsigned)grid), dim3(1024), shm, (hipStream_t)stream, d_indices, d_blk_cell0, n_blocks,
+                     n_genes, n_ranges, d_rowsplit, d_blk_cnt);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
-int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
-                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, const uint32_t *d_rowsplit, uint16_t *d_blk_cnt,
-                         void *stream) {
-  MM_ARG(d_indptr && d_indices && d_cell_order && d_blk_cell0 && d_rowsplit && d_blk_cnt);
-  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_genes <= 65536 && n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
-  if (n_blocks == 0) return MM_OK;
-  return sell_ranges_launch(false, d_indptr, d_indices, nullptr, d_cell_order, d_blk_cell0, n_blocks, n_genes, n_ranges, d_rowsplit,
-                            d_blk_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
-}
-
 int mm_sell_scatter_ranges(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
                            const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges,
-                           const uint32_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,
+                           const int64_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,
                            uint32_t *d_ent, int32_t *d_status, void *stream) {
-  MM_ARG(d_indptr && d_indices && d_data && d_cell_order && d_blk_cell0 && d_rowsplit && d_rank && d_slice_ptr && d_blk_base && d_ent);
+  (void)d_indptr;
+  (void)d_cell_order;
+  MM_ARG(d_indices && d_data && d_blk_cell0 && d_rowsplit && d_rank && d_slice_ptr && d_blk_base && d_ent);
   MM_ARG(d_status && n_blocks >= 0 && n_genes > 0 && n_genes <= 65536 && n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
   if (n_blocks == 0) return MM_OK;
-  return sell_ranges_launch(true, d_indptr, d_indices, d_data, d_cell_order, d_blk_cell0, n_blocks, n_genes, n_ranges, d_rowsplit,
-                            nullptr, d_rank, d_slice_ptr, d_blk_base, d_ent, d_status, stream);
+  int32_t n_slices = (n_genes + 63) / 64;
+  int32_t ngr_max = n_genes / n_ranges + 1;
+  size_t shm = (size_t)ngr_max * (16 + 4 + 8) + 8;       // group buffer + cursor + destination per gene of the range
+  MM_ARG(shm <= 150 * 1024);
+  int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
+  MM_ARG(grid < 2147483647LL);
+  MM_HIP(hipFuncSetAttribute((const void *)k_sell_scatter_quads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_sell_scatter_quads, dim3((unsigned)grid), dim3(64 * RS_WAVES), shm, (hipStream_t)stream, d_indices, d_data,
+                     d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_rank, d_slice_ptr, d_blk_base, d_ent, d_status);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
 }
 
 }  // extern "C"

@@ -97,7 +97,7 @@ NPY_HD double btpe_stirling(double x, double x2) {
 template <typename Int>
 NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q);
 
-template <typename Int, bool FAST = false>
+template <typename Int>
 NPY_HD Int binomial_btpe(Pcg64 &g, Int n, double p) {
   double r = p < 1.0 - p ? p : 1.0 - p;
   double q = 1.0 - r;
@@ -141,12 +141,6 @@ NPY_HD Int binomial_btpe(Pcg64 &g, Int n, double p) {
     Int k = y > m ? y - m : m - y;
     if (!((k > 20) && ((double)k < nrq / 2.0 - 1))) {
       // explicit evaluation of f(y)/f(m)
-      if (FAST) {
-        int dec = btpe_explicit_fast<Int>(v, n, m, y, r, q);
-        if (dec == 0) continue;
-        if (dec == 1) break;
-        NPY_NOTE_FALLBACK(1);
-      }
       double s = r / q;
       double aa = s * ((double)n + 1.0);
       double F = 1.0;
@@ -237,11 +231,43 @@ NPY_HD Int binomial_inversion_pre(Pcg64 &g, Int n, double p, double lq, double U
 NPY_HD float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 NPY_HD float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 NPY_HD float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#elif defined(NPY_HOST_PERTURB)
+// host stress tests only: every cheap primitive is given a relative error of the size the hardware instruction may have
+// (alternating sign), so that the guards are exercised against worse arithmetic than the host's correctly rounded one
+static int npy_pert_flip = 0;
+NPY_HD float npy_pert(float x, float rel) { npy_pert_flip ^= 1; return x * (1.0f + (npy_pert_flip ? rel : -rel)); }
+NPY_HD float f_rcp(float x) { return npy_pert(1.0f / x, 2.4e-7f); }
+NPY_HD float f_exp(float x) { return npy_pert(exp2f(x * 1.44269504088896341f), 4e-7f); }
+NPY_HD float f_sqrt(float x) { return npy_pert(sqrtf(x), 2.4e-7f); }
 #else
 NPY_HD float f_rcp(float x) { return 1.0f / x; }
 NPY_HD float f_exp(float x) { return exp2f(x * 1.44269504088896341f); }
 NPY_HD float f_sqrt(float x) { return sqrtf(x); }
 #endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+NPY_HD double d_rcp(double x) {               // v_rcp_f64 + one Newton step: a few ulp (the IEEE division is ~14 instructions)
+  double r = __builtin_amdgcn_rcp(x);
+  return r + r * (1.0 - x * r);
+}
+NPY_HD float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }   // v_log_f32 (log2)
+#elif defined(NPY_HOST_PERTURB)
+NPY_HD double d_rcp(double x) { npy_pert_flip ^= 1; return (1.0 / x) * (1.0 + (npy_pert_flip ? 1e-15 : -1e-15)); }
+NPY_HD float f_log(float x) { npy_pert_flip ^= 1; return logf(x) * (1.0f + (npy_pert_flip ? 4e-7f : -4e-7f)) + (npy_pert_flip ? 1.5e-7f : -1.5e-7f); }
+#else
+NPY_HD double d_rcp(double x) { return 1.0 / x; }
+NPY_HD float f_log(float x) { return logf(x); }
+#endif
+// log(1 + d) for |d| <= 0.35 with ~2e-7 RELATIVE accuracy (also for tiny d, where log(1 + d) in fp32 would lose everything):
+// 2 atanh(d / (2 + d))
+NPY_HD float f_log1p_small(float d) {
+  float t = d * f_rcp(2.0f + d), t2 = t * t;
+  return 2.0f * t * (1.0f + t2 * (0.333333333f + t2 * (0.2f + t2 * (0.142857143f + t2 * 0.111111111f))));
+}
+NPY_HD float f_stirling(float x) {            // btpe_stirling in fp32: ~1/(12 x), a small correction term
+  float ix = f_rcp(x), ix2 = ix * ix;
+  return (13680.0f - (462.0f - (132.0f - (99.0f - 140.0f * ix2) * ix2) * ix2) * ix2) * ix * (1.0f / 166320.0f);
+}
 
 #ifndef NPY_INV_GUARD
 #define NPY_INV_GUARD 1.5e-4f // absolute, on U - CDF.  fp32 error of exp + recurrence + running subtraction: worst-case bound 4e-5 for X <= 60, largest seen in 2e7 random draws 8e-6
@@ -268,6 +294,9 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
   int32_t cap = (int32_t)capf;
   float Uf = (float)U, px = qn;
   int32_t X = 0;
+#ifdef NPY_ABLATE_INV_LOOP  // timing experiments only: wrong results
+  return (int32_t)(Uf > px) + (cap < 0);
+#endif
   while (Uf > px) {
     X++;
     if (X > cap) return -1;
@@ -299,6 +328,101 @@ NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q)
   return d > 0.0f ? 0 : 1;
 }
 
+// BTPE with numpy's decisions but cheaper arithmetic: the set-up quotients through d_rcp (fp64, a few ulp), the logarithms,
+// the explicit product and the Stirling bound in fp32, every comparison and every floor() guarded by a margin several times the
+// worst-case error of the cheaper arithmetic.  Returns the draw y >= 0, having consumed exactly the uniforms numpy consumes, or -1
+// when some decision fell inside its guard: the caller then restores the generator and runs binomial_btpe (numpy's arithmetic).
+template <typename Int>
+NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r) {   // r = p <= 0.5
+  const double q = 1.0 - r;
+  const double fm = (double)n * r + r;
+  const Int m = (Int)floor(fm);
+  const double md = (double)m;
+  const double nrq = (double)n * r * q;
+  const double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;      // integers are decided in numpy's own arithmetic
+  const double xm = md + 0.5, xl = xm - p1, xr = xm + p1;
+  const double c = 0.134 + 20.5 * d_rcp(15.3 + md);
+  double a = (fm - xl) * d_rcp(fm - xl * r);
+  const double laml = a * (1.0 + a * 0.5);
+  a = (xr - fm) * d_rcp(xr * q);
+  const double lamr = a * (1.0 + a * 0.5);
+  const double rlaml = d_rcp(laml), rlamr = d_rcp(lamr), rc = d_rcp(c), rp1 = d_rcp(p1);
+  const double p2 = p1 * (1.0 + 2.0 * c);
+  const double p3 = p2 + c * rlaml;
+  const double p4 = p3 + c * rlamr;
+  const double gu = 1e-11 * p4;                                       // set-up values are within ~1e-15 (relative) of numpy's
+  const float rnrq = f_rcp((float)nrq);
+  for (int attempt = 0; attempt < 16; attempt++) {
+    double u = pcg64_next_double(g) * p4;
+    double v = pcg64_next_double(g);
+    if (fabs(u - p1) < gu || fabs(u - p2) < gu || fabs(u - p3) < gu) return -1;
+    double x, gx;
+    if (u <= p1) {                       // triangular region: accepted at once
+      x = xm - p1 * v + u;
+      gx = 1e-10 * (fabs(x) + 1.0);
+    } else if (u <= p2) {                // parallelogram
+      x = xl + (u - p1) * rc;
+      v = v * c + 1.0 - fabs(md - x + 0.5) * rp1;
+      if (fabs(v - 1.0) < 1e-10) return -1;
+      if (v > 1.0) continue;
+      gx = 1e-10 * (fabs(x) + 1.0);
+    } else {                             // exponential tails: fp32 logarithm
+      if (v == 0.0) continue;
+      float lv = f_log((float)v);
+      bool left = u <= p3;
+      double rl = left ? rlaml : rlamr;
+      x = left ? xl + (double)lv * rl : xr - (double)lv * rl;
+      gx = (2e-6 * fabs((double)lv) + 4e-7) * rl + 1e-10 * (fabs(x) + 1.0);
+      v = left ? v * (u - p2) * laml : v * (u - p3) * lamr;
+    }
+    double fx = floor(x);
+    if (x - fx < gx || fx + 1.0 - x < gx) return -1;
+    if (fx < 0.0 || fx > (double)n) {
+      if (u <= p2) return -1;            // cannot happen inside the two central regions; be safe
+      continue;                          // numpy: y < 0 (left tail) / y > n (right tail)
+    }
+    Int y = (Int)fx;
+    if (u <= p1) return y;
+    Int k = y > m ? y - m : m - y;
+    if (!((k > 20) && ((double)k < nrq / 2.0 - 1))) {
+      int dec = btpe_explicit_fast<Int>(v, n, m, y, r, q);
+      if (dec < 0) return -1;
+      if (dec == 0) continue;
+      return y;
+    }
+    // squeeze, then the Stirling-corrected bound
+    if (v < 1e-11) {
+      if (v > -1e-11) return -1;
+      return y;                          // numpy: log of a negative number is NaN, every comparison fails, the draw is accepted
+    }
+    float kf = (float)k;
+    float rho = (kf * rnrq) * ((kf * (kf * 0.333333333f + 0.625f) + 0.16666666666666666f) * rnrq + 0.5f);
+    float t = -(kf * kf) * 0.5f * rnrq;
+    float A = f_log((float)v);
+    float gs = 1e-5f * (1.0f + fabsf(A)) + 6e-6f * (fabsf(t) + rho);
+    float lo_ = t - rho, hi_ = t + rho;
+    if (A < lo_ - gs) return y;
+    if (A > hi_ + gs) continue;
+    if (A < lo_ + gs || A > hi_ - gs) return -1;
+    float yf1 = (float)y + 1.0f;                                        // x1
+    float d1 = (float)(m - y) * f_rcp(yf1);                             // f1/x1 - 1 = (m - y)/(y + 1)
+    float wf = (float)(n - y) + 1.0f;                                   // w
+    float d2 = (float)(y - m) * f_rcp(wf);                              // z/w - 1 = (y - m)/(n - y + 1)
+    double num3 = ((double)n + 2.0) * r - ((double)y + 1.0);            // w r - x1 q, without the cancellation
+    float d3 = (float)num3 * f_rcp(yf1 * (float)q);                     // w r/(x1 q) - 1
+    if (fabsf(d1) > 0.35f || fabsf(d2) > 0.35f || fabsf(d3) > 0.35f) return -1;
+    float T1 = (float)xm * f_log1p_small(d1);
+    float T2 = ((float)(n - m) + 0.5f) * f_log1p_small(d2);
+    float T3 = (float)(y - m) * f_log1p_small(d3);
+    float bound = T1 + T2 + T3 + f_stirling((float)m + 1.0f) + f_stirling((float)(n - m) + 1.0f) + f_stirling(yf1) + f_stirling(wf);
+    float gb = 4e-6f * (fabsf(T1) + fabsf(T2) + fabsf(T3)) + 1e-5f * (1.0f + fabsf(A));
+    if (A > bound + gb) continue;
+    if (A < bound - gb) return y;
+    return -1;
+  }
+  return -1;
+}
+
 // binomial(pk, n) with lq = binomial_lq(pk) precomputed; identical draws to binomial(g, pk, n).  FAST selects the guarded
 // fp32 evaluation of the two search loops (same draws, fewer instructions); FAST = false is numpy's arithmetic throughout.
 template <typename Int, bool FAST = false>
@@ -316,7 +440,17 @@ NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
 #ifdef NPY_ABLATE_BTPE  // timing experiments only: wrong results
     X = (Int)((double)n * p);
 #else
-    X = binomial_btpe<Int, FAST>(g, n, p);
+    if (FAST) {
+      Pcg64 saved = g;
+      X = binomial_btpe_fast<Int>(g, n, p);
+      if (X < 0) {
+        NPY_NOTE_FALLBACK(1);
+        g = saved;
+        X = binomial_btpe<Int>(g, n, p);
+      }
+    } else {
+      X = binomial_btpe<Int>(g, n, p);
+    }
 #endif
   }
   return flip ? n - X : X;

@@ -211,7 +211,7 @@ class CountBlocks:
         # that a (row, range) segment is about one wave wide.
         n_sel = len(self.cell_order)
         R = int(min(16, G, max(1, -(-int(csr.nnz) // (56 * max(1, csr.shape[0]))))))
-        rowsplit = empty((max(1, n_sel), R + 1), torch.int32)
+        rowsplit = empty((max(1, n_sel), R + 1), torch.int64)
         call("mm_sell_split", P(csr.indptr), P(csr.indices), P(self.d_cell_order), n_sel, G, R, P(rowsplit), P(status), s)
         self.ranged = (int(status.item()) & 2) == 0
         if self.ranged:

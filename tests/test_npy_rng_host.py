@@ -21,6 +21,16 @@ def shim(tmp_path_factory):
     return ctypes.CDLL(str(out))
 
 
+@pytest.fixture(scope="module")
+def shim_perturbed(tmp_path_factory):
+    """The same header with every cheap primitive of the guarded fast paths perturbed by 2-4x the hardware instruction's error."""
+    out = tmp_path_factory.mktemp("shim_p") / "libnpyrng_host_p.so"
+    src = os.path.join(ROOT, "tests", "host_shim", "npy_rng_host.cpp")
+    inc = os.path.join(ROOT, "scrna_parameter_estimation_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-DNPY_HOST_PERTURB", "-fPIC", "-shared", "-I", inc, src, "-o", str(out)])
+    return ctypes.CDLL(str(out))
+
+
 def pcg_state(seed):
     s = np.random.PCG64(seed).state["state"]
     m = (1 << 64) - 1
@@ -132,3 +142,34 @@ def test_guarded_fast_multinomial_stress(shim):
     assert draws > 4_000_000
     print(f"\n{draws} draws: inversion fallbacks {inv_fb} ({inv_fb / draws:.2e}), explicit-product fallbacks {f_fb} ({f_fb / draws:.2e})")
     assert inv_fb < 5e-3 * draws and f_fb < 5e-3 * draws
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_guarded_fast_btpe_never_disagrees_with_exact_btpe(tmp_path, perturb):
+    """binomial_btpe_fast (fp64 set-up through fast reciprocals, fp32 logarithms / explicit product / Stirling bound, every decision
+    guarded) vs the exact BTPE on ~6e6 random (n, p, state) over n in [60, 2^31), p in (0, 0.5]: whenever the fast path returns a
+    draw, the draw and the generator state after it are identical; it decides > 99 % of the draws.  With ``perturb`` every cheap
+    primitive carries 2-4x the error of the hardware instruction it maps to on the GPU."""
+    exe = tmp_path / "btpe_stress"
+    src = os.path.join(ROOT, "tests", "host_shim", "btpe_stress.cpp")
+    inc = os.path.join(ROOT, "scrna_parameter_estimation_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", inc] + (["-DNPY_HOST_PERTURB"] if perturb else []) + [src, "-o", str(exe)])
+    r = subprocess.run([str(exe), "6000000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    words = r.stdout.split()
+    assert "mismatches 0" in r.stdout and float(words[words.index("fast-decided") + 2].strip("()")) > 0.99, r.stdout
+
+
+def test_guarded_fast_multinomial_with_perturbed_primitives(shim_perturbed):
+    """The guards, not the host's correctly rounded arithmetic, carry the exactness: with every fp32 / fast-reciprocal primitive
+    perturbed the multinomial weights are still numpy's."""
+    rng = np.random.default_rng(12)
+    for trial in range(25):
+        d = int(rng.integers(40, 300))
+        mult = np.concatenate([rng.integers(100, 9000, size=d // 3), rng.integers(1, 100, size=d - d // 3)])
+        rng.shuffle(mult)
+        n = int(mult.sum())
+        pv = mult / mult.sum()
+        ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=300)
+        got = _multi(shim_perturbed, 5, n, pv, 300, "host_multinomial_fast")
+        np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial}")
