@@ -297,13 +297,17 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
 #ifdef NPY_ABLATE_INV_LOOP  // timing experiments only: wrong results
   return (int32_t)(Uf > px) + (cap < 0);
 #endif
-  while (Uf > px) {
-    X++;
-    if (X > cap) return -1;
+  // fully unrolled (cap <= 60): the step number is a compile-time constant, so 1/X and (float)X are literals and an iteration is
+  // five full-rate fp32 instructions (no conversion, no v_rcp_f32); lock-stepped lanes share the trip count anyway
+  const float nf1 = nf + 1.0f;
+#pragma unroll
+  for (int it = 1; it <= 60; it++) {
+    if (!(Uf > px) || it > cap) break;
+    X = it;
     Uf -= px;
-    px = px * ((nf - (float)X + 1.0f) * s) * f_rcp((float)X);
+    px = px * ((nf1 - (float)it) * s) * (1.0f / (float)it);
   }
-  bool ok = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);
+  bool ok = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);   // also false when the search stopped at the cap
   return ok ? X : -1;
 }
 
@@ -312,12 +316,22 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
 template <typename Int>
 NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q) {
   Int k = y > m ? y - m : m - y;
-  if (k > 64) return -1;
+  if (k > 64 || m > (Int)8000000) return -1;      // (consecutive integers must be exact in fp32 for the running index below)
   float s = (float)r * f_rcp((float)q);
   float aa = s * ((float)n + 1.0f);
   Int lo = m < y ? m : y;
-  float P = 1.0f;
-  for (Int i = lo + 1; i <= lo + k; i++) P *= (aa * f_rcp((float)i) - s);   // every factor is ~ (1 - r)/q +- small: no cancellation
+  // P = prod (aa/i - s) = prod (aa - s i)/i as a quotient of two running products, both scaled by 1/m so that every factor is ~1:
+  // four full-rate instructions per factor, no reciprocal inside the loop
+  float ic = f_rcp((float)m + 0.5f);
+  float aa_c = aa * ic, s_c = s * ic;
+  float i_f = (float)lo;
+  float Pn = 1.0f, Pd = 1.0f;
+  for (Int i = 0; i < k; i++) {
+    i_f += 1.0f;
+    Pn *= aa_c - s_c * i_f;
+    Pd *= i_f * ic;
+  }
+  float P = Pn * f_rcp(Pd);
   float vf = (float)v;
   // m < y: F = P;  m > y: F = 1/P (P > 0), compare v*P with 1
   float a_ = m <= y ? vf : vf * P;
