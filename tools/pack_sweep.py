@@ -1,6 +1,6 @@
 """Sweep of the replay kernel's lane-packing constants (engine.PACK_C0 / PACK_C1 / PACK_WAVES) on one shape, in ONE process.
 These are module attributes the tools set directly; the product path reads no environment variable.
-usage: python tools/pack_sweep.py [config=C3] "c0,c1,waves" ["c0,c1,waves" ...]"""
+usage: python tools/pack_sweep.py [config=C3] "c0,c1,waves[,max_resident[,pair_slots]]" ..."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch, scipy.sparse as sp
@@ -26,8 +26,11 @@ skip = ~(bs.K >= 2)
 r = np.random.default_rng(0).random((2, bs.n_pairs))
 bs.alloc_outputs(np.zeros(bs.n_pairs), np.zeros(bs.n_pairs))
 timer = ctypes.c_void_p(); _lib.call("mm_timer_create", ctypes.byref(timer)); s = engine._stream(); ms = ctypes.c_float()
-for c0, c1, waves in combos:
+for combo in combos:
+    c0, c1, waves = combo[:3]
     engine.PACK_C0, engine.PACK_C1, engine.PACK_WAVES = float(c0), float(c1), int(waves)
+    engine.PACK_MAX_RESIDENT = int(combo[3]) if len(combo) > 3 else 2048
+    engine.PAIR_SLOTS = int(combo[4]) if len(combo) > 4 else 1024
     _lib.call("mm_timer_begin", timer, s)
     bs.run(skip, r[0], r[1], m["mv_regressor"]["all"], fill_mode=1)
     _lib.call("mm_timer_end", timer, s)
