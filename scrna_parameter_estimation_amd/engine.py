@@ -210,7 +210,9 @@ class CountBlocks:
         # range), so a row contributes one contiguous segment and the block's open lines complete in one XCD's L2.  R ranges so
         # that a (row, range) segment is about one wave wide.
         n_sel = len(self.cell_order)
-        R = int(min(16, G, max(1, -(-int(csr.nnz) // (56 * max(1, csr.shape[0]))))))
+        R = max(1, -(-int(csr.nnz) // (56 * max(1, csr.shape[0]))))      # ~one wave per (row, range) segment
+        R = max(R, -(-G // 5000))                                          # a range's per-gene state (28 B / gene) must fit the LDS
+        R = int(min(32, G, max(R, 1)))
         rowsplit = empty((max(1, n_sel), R + 1), torch.int64)
         call("mm_sell_split", P(csr.indptr), P(csr.indices), P(self.d_cell_order), n_sel, G, R, P(rowsplit), P(status), s)
         self.ranged = (int(status.item()) & 2) == 0

@@ -233,3 +233,21 @@ def test_ingest_is_deterministic_and_cell_ordered(eng):
                 e = rows[:, ln, :].reshape(-1)
                 e = e[e != 0]
                 assert (np.diff((e & 8191).astype(np.int64)) > 0).all()
+
+
+def test_ingest_with_many_genes_and_very_sparse_rows(eng):
+    """36k genes, ~12 non-zeros per row: the number of gene ranges is set by the LDS budget of a range, not by the row length."""
+    rng = np.random.default_rng(5)
+    n, G = 3000, 36000
+    rows = np.repeat(np.arange(n), 12)
+    cols = rng.integers(0, G, size=n * 12)
+    X = sp.csr_matrix((np.ones(n * 12, dtype=np.float32), (rows, cols)), shape=(n, G))
+    X.sum_duplicates()
+    gid = rng.integers(0, 2, size=n).astype(np.int32)
+    blocks = eng.CountBlocks(eng.DeviceCSR(X), gid, 2)
+    assert blocks.ranged
+    S, sumx, maxx = blocks.moments(np.ones(n))
+    for k in range(2):
+        want = np.asarray(X[gid == k].sum(axis=0)).ravel()
+        np.testing.assert_array_equal(sumx[k], want.astype(np.uint64))
+        np.testing.assert_array_equal(S[0, k], want)
