@@ -15,7 +15,6 @@ genes x genes covariance and scipy's nbinom.ppf) is not built.  Random draws are
 analysis/simulation/estimator_validation.ipynb does).  ``sequencing_sampling`` is dead code in the reference (:118-128).
 """
 
-from ctypes import c_void_p
 
 import numpy as np
 import scipy.stats as stats
