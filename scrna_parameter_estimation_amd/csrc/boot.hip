@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
   }
   npyrng::Pcg64 g{st0, st1, st2, st3};
   const bool run = K >= 2;
+#ifdef BOOT_STAMPS
+  uint64_t stamp_inv = 0, stamp_btpe = 0, stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
   // operands of the NEXT bin step are loaded while the current one computes (one lane = one latency-bound
   // sequential chain, so an exposed L2/HBM round trip per step would be a large part of the step)
   const int64_t obase = row0 * 64 + lane;
@@ -76,7 +79,35 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
         if (k < K - 1) {
           w = 0;
           if (live) {
+#ifdef BOOT_STAMPS  // diagnostic build only (tools/replay_stamps.sh): where a wave-step spends its cycles.  Same draws.
+            {
+              uint64_t s0 = __builtin_amdgcn_s_memtime();
+              bool flip = !(c_pk <= 0.5);
+              double p = flip ? 1.0 - c_pk : c_pk;
+              int32_t X = 0;
+              bool zero = (dn == 0 || c_pk == 0.0), inv = !zero && (p * (double)dn <= 30.0);
+              if (inv) {
+                double U = npyrng::pcg64_next_double(g);
+                int32_t xf = FAST ? npyrng::binomial_inversion_fast<int32_t>(U, dn, p, c_lq) : -1;
+                X = xf >= 0 ? xf : npyrng::binomial_inversion_pre<int32_t>(g, dn, p, c_lq, U);
+              }
+              uint64_t s1 = __builtin_amdgcn_s_memtime();
+              if (!zero && !inv) {
+                npyrng::Pcg64 saved = g;
+                X = FAST ? npyrng::binomial_btpe_fast<int32_t>(g, dn, p) : -1;
+                if (X < 0) {
+                  g = saved;
+                  X = npyrng::binomial_btpe<int32_t>(g, dn, p);
+                }
+              }
+              uint64_t s2 = __builtin_amdgcn_s_memtime();
+              stamp_inv += s1 - s0;
+              stamp_btpe += s2 - s1;
+              w = zero ? 0 : (flip ? dn - X : X);
+            }
+#else
             w = npyrng::binomial_pre<int32_t, FAST>(g, c_pk, c_lq, dn);
+#endif
             dn -= w;
             if (dn <= 0) live = false;
           }
@@ -103,6 +134,15 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
       ov[r] = var;
     }
   }
+#ifdef BOOT_STAMPS
+  if (wave_clock && lane == 0) {  // shader-clock cycles: total, inside the inversion sampler, inside BTPE (wave_clock slots 2, 3 reused)
+    wave_clock[tile * 4 + 0] = t_start;
+    wave_clock[tile * 4 + 1] = (int64_t)(__builtin_amdgcn_s_memtime() - stamp_t0);
+    wave_clock[tile * 4 + 2] = (int64_t)stamp_inv;
+    wave_clock[tile * 4 + 3] = (int64_t)stamp_btpe;
+    return;
+  }
+#endif
   if (wave_clock && lane == 0) {  // profiling hook (mm_debug_wave_clock): when and where this wave ran
     wave_clock[tile * 4 + 0] = t_start;
     wave_clock[tile * 4 + 1] = (int64_t)wall_clock64();

@@ -25,9 +25,9 @@ PACK_C0 = 220.0
 PACK_C1 = 3.0
 PACK_WAVES = 2000
 # (b) measured time of one bin step of a wave of L chains running as the OLDER wave of its SIMD, us (tools/replay_balance.py,
-# C3): used to rank tiles by length for the dispatch order (pair_tiles)
+# C3, round-2 kernel with the guarded fp32 search loops): used to rank tiles by length for the dispatch order (pair_tiles)
 _PACK_L = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 56, 64)
-_PACK_US = (1.34, 1.91, 2.35, 2.60, 2.86, 3.13, 3.29, 3.51, 3.88, 4.18, 4.40, 4.58, 4.70, 4.80, 5.25, 5.68, 6.08, 6.44, 6.7, 7.0, 7.25, 7.7, 8.1)
+_PACK_US = (0.96, 1.30, 1.52, 1.72, 1.87, 1.97, 2.09, 2.20, 2.39, 2.56, 2.74, 2.83, 2.99, 3.13, 3.32, 3.55, 3.67, 3.79, 3.90, 4.05, 4.17, 4.50, 4.81)
 PACK_COST = np.interp(np.arange(1, 65), _PACK_L, _PACK_US)
 # (c) many-chain regime (more tiles than resident wave slots): 2 x 1024 slots; a SIMD retires ~1.46 lone-wave-seconds of tile
 # time per second (older wave 1.0 + younger ~0.46); a tile may take at most PACK_TAIL of the work-bound run time

@@ -1,0 +1,41 @@
+"""Diagnostic build only (library built with -DBOOT_STAMPS): share of a wave's shader cycles inside the inversion sampler, inside
+BTPE and elsewhere (operand loads, moment accumulation, loop control), by tile width.  usage: python tools/replay_stamps.py [config]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pandas as pd, torch, scipy.sparse as sp
+import bench
+from scrna_parameter_estimation_amd import AnnDataLite, engine, memento, _lib
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+cfg = bench.CONFIGS[name]
+N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
+ng = cfg["n_cond"] * cfg["n_rep"]
+csr = bench.synth_device_csr(cfg, 20250117, torch)
+grp = np.random.default_rng(20250117).integers(0, ng, size=N)
+obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
+adata = AnnDataLite(sp.csr_matrix((N, G), dtype=np.float32), obs, pd.DataFrame(index=[f"g{i}" for i in range(G)]))
+memento.setup_memento(adata, q_column="q", device_csr=csr)
+memento.create_groups(adata, label_columns=["cond", "rep"])
+memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+m = adata.uns["memento"]; st = m["_hip"]
+gq = np.array([m["group_q"][g] for g in m["groups"]])
+bs = engine.Bootstrap1D(st.blocks, st.gene_idx, st.maxx, st.sf_bin, st.sf_table, gq, B)
+skip = ~(bs.K >= 2)
+r = np.random.default_rng(0).random((2, bs.n_pairs))
+bs.alloc_outputs(np.zeros(bs.n_pairs), np.zeros(bs.n_pairs))
+buf = torch.zeros((1 << 16) * 4, dtype=torch.int64, device="cuda")
+_lib.call("mm_debug_wave_clock", engine.P(buf))
+bs.run(skip, r[0], r[1], m["mv_regressor"]["all"], fill_mode=1)
+torch.cuda.synchronize()
+_lib.call("mm_debug_wave_clock", None)
+nt = bs.n_tiles
+wc = buf.cpu().numpy().reshape(-1, 4)[:nt].astype(np.float64)
+lanes = (bs.slot_K.reshape(nt, 64) > 0).sum(axis=1)
+steps = np.diff(bs.tile_ptr) * B
+tot, inv, bt = wc[:, 1], wc[:, 2], wc[:, 3]
+print(f"{name}: tiles {nt}; cycles per wave-step by tile width (total | inversion sampler | BTPE | rest):")
+for lo, hi in ((1, 2), (2, 8), (8, 24), (24, 48), (48, 65)):
+    sel = (lanes >= lo) & (lanes < hi)
+    if sel.any():
+        t, i, b = (tot[sel] / steps[sel]).mean(), (inv[sel] / steps[sel]).mean(), (bt[sel] / steps[sel]).mean()
+        print(f"  lanes [{lo},{hi}): {sel.sum():5d} waves  {t:8.0f} | {i:7.0f} ({i / t:.0%}) | {b:7.0f} ({b / t:.0%}) | {t - i - b:7.0f} ({(t - i - b) / t:.0%})")
