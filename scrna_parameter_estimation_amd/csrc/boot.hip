@@ -61,6 +61,9 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
   const bool run = K >= 2;
 #ifdef BOOT_STAMPS
   uint64_t stamp_inv = 0, stamp_btpe = 0, stamp_t0 = __builtin_amdgcn_s_memtime();
+  uint64_t stamp_fastcall = 0;                       // wave time inside the fast BTPE call (the rest of stamp_btpe is the exact redo)
+  uint64_t cnt_bt = 0, cnt_fb = 0;                   // BTPE draws of this lane / of them redone in the exact arithmetic
+  uint64_t stamp_bt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // inside the fast BTPE: set-up | uniforms | regions | floor + k | explicit product | squeeze | Stirling
 #endif
   // operands of the NEXT bin step are loaded while the current one computes (one lane = one latency-bound
   // sequential chain, so an exposed L2/HBM round trip per step would be a large part of the step)
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
           if (live) {
 #ifdef BOOT_STAMPS  // diagnostic build only (tools/replay_stamps.sh): where a wave-step spends its cycles.  Same draws.
             {
-              uint64_t s0 = __builtin_amdgcn_s_memtime();
+              uint64_t s0, s1, s2;
+              NPY_CLOCK(s0);
               bool flip = !(c_pk <= 0.5);
               double p = flip ? 1.0 - c_pk : c_pk;
               int32_t X = 0;
@@ -91,16 +95,23 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
                 int32_t xf = FAST ? npyrng::binomial_inversion_fast<int32_t>(U, dn, p, c_lq) : -1;
                 X = xf >= 0 ? xf : npyrng::binomial_inversion_pre<int32_t>(g, dn, p, c_lq, U);
               }
-              uint64_t s1 = __builtin_amdgcn_s_memtime();
-              if (!zero && !inv) {
-                npyrng::Pcg64 saved = g;
-                X = FAST ? npyrng::binomial_btpe_fast<int32_t>(g, dn, p) : -1;
-                if (X < 0) {
-                  g = saved;
-                  X = npyrng::binomial_btpe<int32_t>(g, dn, p);
-                }
+              NPY_CLOCK(s1);
+              npyrng::Pcg64 saved = g;
+              bool bt = !zero && !inv;
+              if (bt) {
+                NPY_CLOCK(stamp_bt[7]);
+                X = FAST ? npyrng::binomial_btpe_fast<int32_t>(g, dn, p, stamp_bt) : -1;
+                cnt_bt++;
               }
-              uint64_t s2 = __builtin_amdgcn_s_memtime();
+              uint64_t s15;
+              NPY_CLOCK(s15);
+              stamp_fastcall += s15 - s1;
+              if (bt && X < 0) {
+                cnt_fb++;
+                g = saved;
+                X = npyrng::binomial_btpe<int32_t>(g, dn, p);
+              }
+              NPY_CLOCK(s2);
               stamp_inv += s1 - s0;
               stamp_btpe += s2 - s1;
               w = zero ? 0 : (flip ? dn - X : X);
@@ -135,11 +146,25 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
     }
   }
 #ifdef BOOT_STAMPS
+  // the inner stamps are accumulated by every lane while it is active in that code; the busiest lane's sum is the (lower bound of
+  // the) wave's time there
+  for (int i = 0; i < 7; i++)
+    for (int off = 32; off > 0; off >>= 1) {
+      uint64_t o = (uint64_t)__shfl_xor((long long)stamp_bt[i], off, 64);
+      stamp_bt[i] = o > stamp_bt[i] ? o : stamp_bt[i];
+    }
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt_bt += (uint64_t)__shfl_xor((long long)cnt_bt, off, 64);
+    cnt_fb += (uint64_t)__shfl_xor((long long)cnt_fb, off, 64);
+  }
+  if (wave_clock && lane == 0) wave_clock[(n_tiles + tile) * 8 + 7] = (int64_t)((cnt_fb << 40) | cnt_bt);
   if (wave_clock && lane == 0) {  // shader-clock cycles: total, inside the inversion sampler, inside BTPE (wave_clock slots 2, 3 reused)
     wave_clock[tile * 4 + 0] = t_start;
     wave_clock[tile * 4 + 1] = (int64_t)(__builtin_amdgcn_s_memtime() - stamp_t0);
     wave_clock[tile * 4 + 2] = (int64_t)stamp_inv;
     wave_clock[tile * 4 + 3] = (int64_t)stamp_btpe;
+    for (int i = 0; i < 6; i++) wave_clock[(n_tiles + tile) * 8 + i] = (int64_t)stamp_bt[i];   // second half of the debug buffer
+    wave_clock[(n_tiles + tile) * 8 + 6] = (int64_t)stamp_fastcall;
     return;
   }
 #endif

@@ -27,6 +27,21 @@
 #pragma clang fp contract(off)
 #endif
 
+#if defined(BOOT_STAMPS) && defined(__HIPCC__)   // diagnostic build: cycle accumulators inside the fast BTPE
+#define NPY_ST_PARAM , uint64_t *npy_st
+#if defined(__HIP_DEVICE_COMPILE__)
+// one asm statement (s_memtime returns out of order with LDS / scalar loads) fenced against instruction scheduling on both sides
+#define NPY_CLOCK(t_) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                           __builtin_amdgcn_sched_barrier(0); } while (0)
+#define NPY_ST(i) do { uint64_t t_; NPY_CLOCK(t_); npy_st[i] += t_ - npy_st[7]; npy_st[7] = t_; } while (0)
+#else
+#define NPY_CLOCK(t_) ((t_) = 0)
+#define NPY_ST(i) (void)npy_st
+#endif
+#else
+#define NPY_ST_PARAM
+#define NPY_ST(i)
+#endif
 #ifndef NPY_NOTE_FALLBACK
 #define NPY_NOTE_FALLBACK(which)   // host tests count how often the guarded fast paths defer to the exact arithmetic
 #endif
@@ -347,7 +362,7 @@ NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q)
 // worst-case error of the cheaper arithmetic.  Returns the draw y >= 0, having consumed exactly the uniforms numpy consumes, or -1
 // when some decision fell inside its guard: the caller then restores the generator and runs binomial_btpe (numpy's arithmetic).
 template <typename Int>
-NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r) {   // r = p <= 0.5
+NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r NPY_ST_PARAM) {   // r = p <= 0.5
   const double q = 1.0 - r;
   const double fm = (double)n * r + r;
   const Int m = (Int)floor(fm);
@@ -366,9 +381,11 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r) {   // r = p <= 0.5
   const double p4 = p3 + c * rlamr;
   const double gu = 1e-11 * p4;                                       // set-up values are within ~1e-15 (relative) of numpy's
   const float rnrq = f_rcp((float)nrq);
+  NPY_ST(0);
   for (int attempt = 0; attempt < 16; attempt++) {
     double u = pcg64_next_double(g) * p4;
     double v = pcg64_next_double(g);
+    NPY_ST(1);
     if (fabs(u - p1) < gu || fabs(u - p2) < gu || fabs(u - p3) < gu) return -1;
     double x, gx;
     if (u <= p1) {                       // triangular region: accepted at once
@@ -389,6 +406,7 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r) {   // r = p <= 0.5
       gx = (2e-6 * fabs((double)lv) + 4e-7) * rl + 1e-10 * (fabs(x) + 1.0);
       v = left ? v * (u - p2) * laml : v * (u - p3) * lamr;
     }
+    NPY_ST(2);
     double fx = floor(x);
     if (x - fx < gx || fx + 1.0 - x < gx) return -1;
     if (fx < 0.0 || fx > (double)n) {
@@ -398,8 +416,10 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r) {   // r = p <= 0.5
     Int y = (Int)fx;
     if (u <= p1) return y;
     Int k = y > m ? y - m : m - y;
+    NPY_ST(3);
     if (!((k > 20) && ((double)k < nrq / 2.0 - 1))) {
       int dec = btpe_explicit_fast<Int>(v, n, m, y, r, q);
+      NPY_ST(4);
       if (dec < 0) return -1;
       if (dec == 0) continue;
       return y;
@@ -415,6 +435,7 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r) {   // r = p <= 0.5
     float A = f_log((float)v);
     float gs = 1e-5f * (1.0f + fabsf(A)) + 6e-6f * (fabsf(t) + rho);
     float lo_ = t - rho, hi_ = t + rho;
+    NPY_ST(5);
     if (A < lo_ - gs) return y;
     if (A > hi_ + gs) continue;
     if (A < lo_ + gs || A > hi_ - gs) return -1;
@@ -430,6 +451,7 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r) {   // r = p <= 0.5
     float T3 = (float)(y - m) * f_log1p_small(d3);
     float bound = T1 + T2 + T3 + f_stirling((float)m + 1.0f) + f_stirling((float)(n - m) + 1.0f) + f_stirling(yf1) + f_stirling(wf);
     float gb = 4e-6f * (fabsf(T1) + fabsf(T2) + fabsf(T3)) + 1e-5f * (1.0f + fabsf(A));
+    NPY_ST(6);
     if (A > bound + gb) continue;
     if (A < bound - gb) return y;
     return -1;
@@ -456,7 +478,12 @@ NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
 #else
     if (FAST) {
       Pcg64 saved = g;
+#if defined(BOOT_STAMPS) && defined(__HIPCC__)
+      uint64_t npy_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      X = binomial_btpe_fast<Int>(g, n, p, npy_dummy);
+#else
       X = binomial_btpe_fast<Int>(g, n, p);
+#endif
       if (X < 0) {
         NPY_NOTE_FALLBACK(1);
         g = saved;
