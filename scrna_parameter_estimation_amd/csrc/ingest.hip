@@ -247,42 +247,50 @@ __global__ __launch_bounds__(1024) void k_sell_scatter(const int64_t *__restrict
 // emits).  The scattered 4-byte stores of k_sell_scatter above re-open every 64-byte line of the block's 20 MB entry region up
 // to 16 times, and with ~17 blocks in flight per XCD those lines do not survive in the 4 MB L2: measured at BASELINE configs[2]
 // (profiles/r02_k1_traffic_C3.json) 18.7 GB written + 17 GB fetched for 2.4 GB of entries.  Here a workgroup owns (block, a
-// contiguous range of gene ids): in a sorted row its entries are ONE contiguous segment, and its per-gene state is a few KB of LDS
-// -- small enough to park every gene's open 16-byte group there (k_sell_scatter_quads) instead of storing entry by entry.
+// range of MM_RANGE_GENES consecutive gene ids): in a sorted row its entries are ONE contiguous segment, and its per-gene state
+// is 48 B x 1024 of LDS -- small enough to assemble every gene's 16-byte groups there instead of storing entry by entry.
 //
 // Step 0: per row, where each gene range starts (R + 1 absolute positions in indices / data), and the structural checks
-// (column indices inside [0, G), strictly ascending).  One wave per row, coalesced index reads, R - 1 ballots per 64 entries.
+// (column indices inside [0, G), strictly ascending).  One wave per row, coalesced index reads; a lane whose range id differs
+// from its predecessor's owns the boundaries in between (no ballots, no search); the row's R + 1 positions leave through LDS
+// as one coalesced store.
 __global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                     const int32_t *__restrict__ cell_order, int64_t n_sel, int32_t n_genes,
                                                     int32_t n_ranges, int64_t *__restrict__ rowsplit, int32_t *__restrict__ status) {
-  __shared__ int32_t bnd[33];                       // bnd[k] = first gene id of range k
-  if (threadIdx.x <= n_ranges) bnd[threadIdx.x] = (int32_t)(((int64_t)threadIdx.x * n_genes) / n_ranges);
-  __syncthreads();
-  int lane = mm_lane();
+  __shared__ volatile int64_t pos[4][MM_MAX_RANGES + 1];
+  int lane = mm_lane(), wv = threadIdx.x >> 6;
   int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int bad = 0;
   for (int64_t r = wave; r < n_sel; r += nwaves) {
     int cell = cell_order[r];
     int64_t s = indptr[cell], e = indptr[cell + 1];
-    // lane k (1 <= k < R) accumulates the number of entries with column < bnd[k]
-    uint32_t mine = 0;
-    int prev_last = -1;
-    for (int64_t i0 = s; i0 < e; i0 += 64) {
+    int prev_g = -1, prev_key = -1;
+    for (int64_t i0 = s; i0 <= e; i0 += 64) {       // position e takes part as the sentinel (range id R)
       int64_t i = i0 + lane;
       int g = i < e ? indices[i] : 0x7fffffff;
-      int gp = __shfl_up(g, 1, 64);
-      if (lane == 0) gp = prev_last;
-      if (i < e && (g < 0 || g >= n_genes || g <= gp)) bad = 1;
-      prev_last = __shfl(g, 63, 64);
-      for (int k = 1; k < n_ranges; k++) {
-        uint64_t bal = __ballot(g < bnd[k]);        // wave-uniform bound (LDS broadcast), one s_bcnt1 per range
-        if (lane == k) mine += (uint32_t)__popcll(bal);
+      int key = n_ranges;
+      if (i < e) {
+        if (g < 0 || g >= n_genes) {
+          bad = 1;
+          g = g < 0 ? 0 : n_genes - 1;
+        }
+        key = g >> MM_RANGE_SHIFT;
       }
+      int gp = __shfl_up(g, 1, 64), kp = __shfl_up(key, 1, 64);
+      if (lane == 0) {
+        gp = prev_g;
+        kp = prev_key;
+      }
+      if (i < e && g <= gp) bad = 1;                // not strictly ascending
+      if (i <= e)
+        for (int k = kp + 1; k <= key; k++) pos[wv][k] = i;   // (an unsorted row may leave holes: it is flagged and not used)
+      prev_g = __shfl(g, 63, 64);
+      prev_key = __shfl(key, 63, 64);
     }
-    if (lane == 0) mine = 0;
-    if (lane == n_ranges) mine = (uint32_t)(e - s);
-    if (lane <= n_ranges) rowsplit[r * (n_ranges + 1) + lane] = s + (int64_t)mine;   // ABSOLUTE position in indices / data
+    __builtin_amdgcn_wave_barrier();   // the same wave wrote and reads pos[wv]: its LDS operations complete in order
+    for (int k = lane; k <= n_ranges; k += 64) rowsplit[r * (n_ranges + 1) + k] = pos[wv][k];
+    __builtin_amdgcn_wave_barrier();
   }
   if (bad) atomicOr(status, 2);
 }
@@ -291,34 +299,32 @@ __global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ 
 __global__ __launch_bounds__(1024) void k_sell_count_ranges(const int32_t *__restrict__ indices, const int32_t *__restrict__ blk_cell0,
                                                             int32_t n_blocks, int32_t n_genes, int32_t n_ranges,
                                                             const int64_t *__restrict__ rowsplit, uint16_t *__restrict__ blk_cnt) {
-  extern __shared__ uint32_t smem[];
+  __shared__ uint32_t cur[MM_RANGE_GENES];               // counts of this range's genes
   // workgroup -> (block, range): the R workgroups of one block get ids that are equal mod 8, i.e. land on one XCD (speed only)
   int x = blockIdx.x & 7, t = blockIdx.x >> 3;
   int b = (t / n_ranges) * 8 + x, rg = t % n_ranges;
   if (b >= n_blocks) return;
-  int g0 = (int)(((int64_t)rg * n_genes) / n_ranges), g1 = (int)(((int64_t)(rg + 1) * n_genes) / n_ranges);
-  int ngr = g1 - g0;
-  uint32_t *cur = smem;                                  // [ngr] counts of this range's genes
+  int g0 = rg << MM_RANGE_SHIFT, ngr = min(MM_RANGE_GENES, n_genes - g0);
   for (int i = threadIdx.x; i < ngr; i += blockDim.x) cur[i] = 0;
   __syncthreads();
   int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
-  int lane = mm_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n_ranges + 1;
-  // one row segment per wave iteration; the NEXT row's segment bounds are fetched while the current one is processed
-  int r = c0 + wave;
+  // a quarter wave per row segment; the NEXT row's segment bounds are fetched while the current one is processed
+  int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
+  int r = c0 + grp;
   int64_t a = 0, z = 0;
   if (r < c1) {
     a = rowsplit[r * ld + rg];
     z = rowsplit[r * ld + rg + 1];
   }
-  for (; r < c1; r += nw) {
-    int rn = r + nw;
+  for (; r < c1; r += ngrp) {
+    int rn = r + ngrp;
     int64_t an = 0, zn = 0;
     if (rn < c1) {
       an = rowsplit[rn * ld + rg];
       zn = rowsplit[rn * ld + rg + 1];
     }
-    for (int64_t i = a + lane; i < z; i += 64) atomicAdd(&cur[indices[i] - g0], 1u);
+    for (int64_t i = a + sub; i < z; i += 16) atomicAdd(&cur[indices[i] - g0], 1u);
     a = an;
     z = zn;
   }
@@ -329,113 +335,228 @@ __global__ __launch_bounds__(1024) void k_sell_count_ranges(const int32_t *__res
 // Step 3, deterministic and write-combined.  Measured on this chip (profiles/README.md, round 2): a 4-byte store to a line that
 // is not being written by the same wave instruction costs ~26 B of HBM write traffic -- stores are written through, L2 does not
 // merge them over time -- so the per-entry scatter above writes 15.9 GB for 2.4 GB of entries even with XCD-local workgroups.
-// Here an entry is first parked in LDS and only complete 16-byte groups (the 4 consecutive entries of one gene = one lane's
-// dwordx4 of a slice row) go to HBM.  To make that race-free WITHOUT atomics a gene belongs to exactly one WAVE: the workgroup owns
-// (block, gene range) as before and wave w of it owns the w-th quarter of that range; every wave walks ALL rows of the block in
-// order, loads the row's range segment (one coalesced load, shared through L1 by the 4 waves) and keeps the lanes whose gene is
-// its own.  Entries of one row have distinct genes, so the lanes of an iteration never collide, and a gene's entries arrive in
-// cell order: the entry order inside a gene is now DETERMINISTIC (ascending cell), as is every fp64 sum K1 forms from it.
-#define RS_WAVES 4
-__global__ __launch_bounds__(64 * RS_WAVES) void k_sell_scatter_quads(const int32_t *__restrict__ indices, const float *__restrict__ data,
-                                                                       const int32_t *__restrict__ blk_cell0, int32_t n_blocks,
-                                                                       int32_t n_genes, int32_t n_slices, int32_t n_ranges,
-                                                                       const int64_t *__restrict__ rowsplit, const int32_t *__restrict__ rank,
-                                                                       const int32_t *__restrict__ slice_ptr, const int64_t *__restrict__ blk_base,
-                                                                       uint32_t *__restrict__ ent, int32_t *__restrict__ status) {
-  extern __shared__ u32x4 smem_q[];                      // 16-byte aligned dynamic LDS (the group buffers are read as dwordx4)
-  uint32_t *smem = (uint32_t *)smem_q;
+// Here the workgroup of (block, gene range) takes the block's rows in TILES of up to 128 rows, and only complete 16-byte groups
+// (4 consecutive entries of one gene = one lane's dwordx4 of a slice row) go to HBM:
+//   P1  every entry of the tile (each handled by exactly one lane) sets bit `row` in its gene's 128-bit row mask (LDS atomicOr:
+//       the result does not depend on the order of arrival);
+//   P2  per gene: popcounts of the four mask words -> entries n of this tile, and an exclusive scan of n over the range's genes
+//       gives the gene's run in the tile buffer;
+//   P3  every entry again: its rank inside the gene = bits below `row` in the mask, so the entry's position in the gene is
+//       cur[gene] + rank -- a pure function of the data, ascending in the cell index -- and it goes to the tile buffer; the entry
+//       that lands on slot 3 of a group files the group for storing;
+//   P4  filed groups are read back (entries of earlier tiles from the gene's 4-slot carry) and stored, one dwordx4 each;
+//   P5  per gene: the open group moves to the carry, cur += n, mask cleared.
+// No entry is ever placed by arrival order: two ingests of one CSR give bit-identical count blocks, hence bit-identical fp64 sums.
+#define MR_T 128          // rows per tile (= bits of the row mask)
+#define MR_EMAX 6144      // entries per tile (tile buffer)
+#define MR_THREADS 512
+#define MR_WAVES (MR_THREADS / 64)
+#define MR_WROWS (MR_T / MR_WAVES)   // 16 rows of a tile per wave
+
+__device__ __forceinline__ int mm_wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  return v;
+}
+
+template <int SUB>   // lanes per row segment (16, 32 or 64): 64 / SUB rows are in flight per wave instruction
+__global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int32_t *__restrict__ indices, const float *__restrict__ data,
+                                                                    const int32_t *__restrict__ blk_cell0, int32_t n_blocks,
+                                                                    int32_t n_genes, int32_t n_slices, int32_t n_ranges,
+                                                                    const int64_t *__restrict__ rowsplit, const int32_t *__restrict__ rank,
+                                                                    const int32_t *__restrict__ slice_ptr, const int64_t *__restrict__ blk_base,
+                                                                    uint32_t *__restrict__ ent, int32_t *__restrict__ status) {
+  extern __shared__ u32x4 smem_q[];
+  u32x4 *mask = smem_q;                                        // [1024] row mask of the tile per gene
+  u32x4 *stage = mask + MM_RANGE_GENES;                        // [1024] carry: the gene's open group (slot = position & 3)
+  int64_t *dst = (int64_t *)(stage + MM_RANGE_GENES);          // [1024] ent index of the gene's entry 0
+  uint32_t *pre = (uint32_t *)(dst + MM_RANGE_GENES);          // [1024] popcount prefixes of the mask words | n << 24
+  uint32_t *co = pre + MM_RANGE_GENES;                         // [1024] cur (entries placed before this tile) | run start << 16
+  uint32_t *tilebuf = co + MM_RANGE_GENES;                     // [MR_EMAX]
+  uint32_t *filed = tilebuf + MR_EMAX;                         // [MR_EMAX / 4] gene | position << 10 of every completed group
+  uint32_t *wtot = filed + MR_EMAX / 4;                        // [MR_WAVES] + [1] number of filed groups
+  uint32_t *nfiled = wtot + MR_WAVES;
+  uint32_t *maskw = (uint32_t *)mask;
+  uint32_t *stagew = (uint32_t *)stage;
+
   int x = blockIdx.x & 7, t = blockIdx.x >> 3;
   int b = (t / n_ranges) * 8 + x, rg = t % n_ranges;
   if (b >= n_blocks) return;
-  int g0 = (int)(((int64_t)rg * n_genes) / n_ranges), g1 = (int)(((int64_t)(rg + 1) * n_genes) / n_ranges);
-  int ngr = g1 - g0;
-  uint32_t *stage = smem;                                // [ngr][4] the open 16-byte group of every gene
-  uint32_t *cur = smem + (size_t)ngr * 4;                // [ngr] entries seen so far
-  int64_t *dst = (int64_t *)(cur + ngr + (ngr & 1));     // [ngr] ent index of the gene's entry 0: (base + sptr[slice])*256 + lane*4
-  for (int i = threadIdx.x; i < ngr; i += blockDim.x) {
-    cur[i] = 0;
-    int sl = rank[(int64_t)b * n_genes + g0 + i];
-    dst[i] = (blk_base[b] + slice_ptr[(int64_t)b * (n_slices + 1) + (sl >> 6)]) * 256 + (sl & 63) * 4;
+  const int tid = threadIdx.x, lane = mm_lane(), wave = tid >> 6;
+  const int g0 = rg << MM_RANGE_SHIFT, ngr = min(MM_RANGE_GENES, n_genes - g0);
+  for (int i = tid; i < MM_RANGE_GENES; i += MR_THREADS) {
+    mask[i] = u32x4{0, 0, 0, 0};
+    stage[i] = u32x4{0, 0, 0, 0};
+    pre[i] = 0;
+    co[i] = 0;
+    int64_t d = 0;
+    if (i < ngr) {
+      int sl = rank[(int64_t)b * n_genes + g0 + i];
+      d = (blk_base[b] + slice_ptr[(int64_t)b * (n_slices + 1) + (sl >> 6)]) * 256 + (sl & 63) * 4;
+    }
+    dst[i] = d;
   }
+  if (tid == 0) *nfiled = 0;
   __syncthreads();
-  int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
-  int lane = mm_lane(), wave = threadIdx.x >> 6;
-  int lo = (int)(((int64_t)wave * ngr) / RS_WAVES), hi = (int)(((int64_t)(wave + 1) * ngr) / RS_WAVES);   // this wave's genes
+  const int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
   const int64_t ld = n_ranges + 1;
+  constexpr int RPS = 64 / SUB;                 // rows per wave instruction
+  constexpr int ITER = MR_WROWS / RPS;
+  const int sl = lane & (SUB - 1), rsub = lane / SUB;
   int bad = 0;
-  // A wave walks the rows strictly in order, so its latency per row is what bounds the kernel: the segment bounds and the first
-  // 64 column indices of the next RS_AHEAD rows are kept in flight (software pipeline in registers).
-#define RS_AHEAD 4
-  int64_t ca[RS_AHEAD], cz[RS_AHEAD], na[RS_AHEAD], nz[RS_AHEAD];
-  int cg[RS_AHEAD];
-  float cd[RS_AHEAD];
-  auto load_bounds = [&](int r0, int64_t *pa, int64_t *pz) {
-#pragma unroll
-    for (int u = 0; u < RS_AHEAD; u++) {
-      int r = r0 + u;
-      pa[u] = pz[u] = 0;
-      if (r < c1) {
-        pa[u] = rowsplit[(int64_t)r * ld + rg];
-        pz[u] = rowsplit[(int64_t)r * ld + rg + 1];
-      }
+
+  for (int r0 = c0; r0 < c1;) {
+    // ---- tile extent: every wave derives it from the same bounds (no exchange): lane L holds rows r0 + L and r0 + 64 + L
+    int64_t a0 = 0, a1 = 0;
+    int l0 = 0, l1 = 0;
+    if (r0 + lane < c1) {
+      a0 = rowsplit[(int64_t)(r0 + lane) * ld + rg];
+      l0 = (int)(rowsplit[(int64_t)(r0 + lane) * ld + rg + 1] - a0);
     }
-  };
-  load_bounds(c0, ca, cz);
-#pragma unroll
-  for (int u = 0; u < RS_AHEAD; u++) {
-    bool in = ca[u] + lane < cz[u];
-    cg[u] = in ? indices[ca[u] + lane] : 0;
-    cd[u] = in ? data[ca[u] + lane] : 1.0f;
-  }
-  load_bounds(c0 + RS_AHEAD, na, nz);
-  for (int r0 = c0; r0 < c1; r0 += RS_AHEAD) {
-    // issued first, consumed in the NEXT pass: the next group's column indices and the bounds of the group after it
-    int ng[RS_AHEAD];
-    float nd[RS_AHEAD];
-    int64_t fa[RS_AHEAD], fz[RS_AHEAD];
-#pragma unroll
-    for (int u = 0; u < RS_AHEAD; u++) {
-      bool in = na[u] + lane < nz[u];
-      ng[u] = in ? indices[na[u] + lane] : 0;
-      nd[u] = in ? data[na[u] + lane] : 1.0f;      // all 64 lanes (the 4 waves share the lines through L1): no dependent load later
+    if (r0 + 64 + lane < c1) {
+      a1 = rowsplit[(int64_t)(r0 + 64 + lane) * ld + rg];
+      l1 = (int)(rowsplit[(int64_t)(r0 + 64 + lane) * ld + rg + 1] - a1);
     }
-    load_bounds(r0 + 2 * RS_AHEAD, fa, fz);
+    int inc0 = mm_wave_incl_scan(l0, lane);
+    int tot0 = __shfl(inc0, 63, 64);
+    int inc1 = tot0 + mm_wave_incl_scan(l1, lane);
+    int T = __popcll(__ballot(inc0 <= MR_EMAX)) + __popcll(__ballot(inc1 <= MR_EMAX));   // cumulative counts are monotone
+    T = min(T, c1 - r0);                         // (>= 1: one segment holds at most 1024 entries)
+    // this wave's rows of the tile: wave * 16 .. + 16, all in the first or all in the second half
+    const int64_t srcA = wave < MR_WAVES / 2 ? a0 : a1;
+    const int srcL = wave < MR_WAVES / 2 ? l0 : l1;
+    const uint32_t cell_base = (uint32_t)(r0 - c0);
+
+    // ---- P1: row masks.  (The segment bounds are re-read from the holding lanes in every phase: three bpermutes are cheaper
+    // than 3 x ITER registers held across the barriers.)
+    int gi[ITER];
+    uint32_t en[ITER];
+    auto seg = [&](int row, int64_t &a, int &len) {
+      a = __shfl(srcA, row & 63, 64);
+      int L = __shfl(srcL, row & 63, 64);
+      len = row < T ? L : 0;
+    };
 #pragma unroll
-    for (int u = 0; u < RS_AHEAD; u++) {
-      int r = r0 + u;
-      if (r < c1) {
-        uint32_t cell_local = (uint32_t)(r - c0);
-        int64_t a = ca[u], z = cz[u];
-        for (int64_t i = a + lane; i < z; i += 64) {
-          bool first = i < a + 64;
-          int gl = (first ? cg[u] : indices[i]) - g0;
-          if (gl >= lo && gl < hi) {
-            float xf = first ? cd[u] : data[i];
-            if (!(xf >= 1.0f && xf <= (float)MM_MAX_COUNT && xf == floorf(xf))) {  // counts: positive integers inside the 19-bit field
-              bad = 1;
-              xf = 1.0f;
-            }
-            uint32_t j = cur[gl];
-            cur[gl] = j + 1;
-            stage[gl * 4 + (j & 3)] = cell_local | ((uint32_t)xf << MM_CELL_BITS);
-            if ((j & 3) == 3) {                            // the group is complete: one 16-byte store
-              u32x4 q = *(const u32x4 *)(stage + gl * 4);
-              *(u32x4 *)(ent + dst[gl] + (int64_t)(j >> 2) * 256) = q;
-            }
-          }
+    for (int it = 0; it < ITER; it++) {
+      int row = wave * MR_WROWS + it * RPS + rsub, len;
+      int64_t a;
+      seg(row, a, len);
+      bool has = sl < len;
+      gi[it] = has ? indices[a + sl] : -1;
+      en[it] = has ? __float_as_uint(data[a + sl]) : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+      int row = wave * MR_WROWS + it * RPS + rsub, len;
+      int64_t a;
+      seg(row, a, len);
+      if (gi[it] >= 0) {
+        float v = __uint_as_float(en[it]);
+        if (!(v >= 1.0f && v <= (float)MM_MAX_COUNT && v == floorf(v))) {   // counts: positive integers inside the 19-bit field
+          bad = 1;
+          v = 1.0f;
         }
+        int gl = gi[it] - g0;
+        gi[it] = gl;
+        en[it] = (cell_base + (uint32_t)row) | ((uint32_t)v << MM_CELL_BITS);
+        atomicOr(&maskw[gl * 4 + (row >> 5)], 1u << (row & 31));
+      }
+      for (int k = sl + SUB; k < len; k += SUB)                              // the rest of a long segment
+        atomicOr(&maskw[(indices[a + k] - g0) * 4 + (row >> 5)], 1u << (row & 31));
+    }
+    __syncthreads();
+
+    // ---- P2: per gene (two per thread): prefixes of the mask popcounts, run starts by a workgroup-wide exclusive scan
+    int ga = tid * 2;
+    u32x4 m0 = mask[ga], m1 = mask[ga + 1];
+    uint32_t p0a = __popc(m0.x), p0b = p0a + __popc(m0.y), p0c = p0b + __popc(m0.z), n0 = p0c + __popc(m0.w);
+    uint32_t p1a = __popc(m1.x), p1b = p1a + __popc(m1.y), p1c = p1b + __popc(m1.z), n1 = p1c + __popc(m1.w);
+    int incl = mm_wave_incl_scan((int)(n0 + n1), lane);
+    if (lane == 63) wtot[wave] = (uint32_t)incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < MR_WAVES; w++) before += w < wave ? wtot[w] : 0;
+    uint32_t off0 = before + (uint32_t)incl - n0 - n1, off1 = off0 + n0;
+    pre[ga] = p0a | (p0b << 8) | (p0c << 16) | (n0 << 24);
+    pre[ga + 1] = p1a | (p1b << 8) | (p1c << 16) | (n1 << 24);
+    co[ga] = (co[ga] & 0xFFFFu) | (off0 << 16);
+    co[ga + 1] = (co[ga + 1] & 0xFFFFu) | (off1 << 16);
+    __syncthreads();
+
+    // ---- P3: place every entry of the tile in its gene's run; slot-3 entries file their group
+    auto place = [&](int gl, int row, uint32_t entry) {
+      uint32_t m = maskw[gl * 4 + (row >> 5)], p = pre[gl], c_o = co[gl];
+      uint32_t w = (uint32_t)row >> 5;
+      uint32_t below = w == 0 ? 0u : (p >> (8 * (w - 1))) & 0xFFu;
+      uint32_t rk = below + __popc(m & ((1u << (row & 31)) - 1u));
+      tilebuf[(c_o >> 16) + rk] = entry;
+      uint32_t j = (c_o & 0xFFFFu) + rk;
+      if ((j & 3u) == 3u) filed[atomicAdd(nfiled, 1u)] = (uint32_t)gl | (j << MM_RANGE_SHIFT);
+    };
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+      int row = wave * MR_WROWS + it * RPS + rsub, len;
+      int64_t a;
+      seg(row, a, len);
+      if (gi[it] >= 0) place(gi[it], row, en[it]);
+      for (int k = sl + SUB; k < len; k += SUB) {
+        float v = data[a + k];
+        if (!(v >= 1.0f && v <= (float)MM_MAX_COUNT && v == floorf(v))) {
+          bad = 1;
+          v = 1.0f;
+        }
+        place(indices[a + k] - g0, row, (cell_base + (uint32_t)row) | ((uint32_t)v << MM_CELL_BITS));
       }
     }
-#pragma unroll
-    for (int u = 0; u < RS_AHEAD; u++) {
-      ca[u] = na[u]; cz[u] = nz[u]; cg[u] = ng[u]; cd[u] = nd[u];
-      na[u] = fa[u]; nz[u] = fz[u];
+    __syncthreads();
+
+    // ---- P4: store the completed groups
+    uint32_t nf = *nfiled;
+    for (uint32_t k = tid; k < nf; k += MR_THREADS) {
+      uint32_t f = filed[k];
+      uint32_t gl = f & (MM_RANGE_GENES - 1), j = f >> MM_RANGE_SHIFT;          // j = position of the group's last entry
+      uint32_t c_o = co[gl], c = c_o & 0xFFFFu, off = c_o >> 16;
+      uint32_t e0 = j - 3u;
+      u32x4 q;
+      q.x = e0 >= c ? tilebuf[off + e0 - c] : stagew[gl * 4 + 0];
+      q.y = e0 + 1 >= c ? tilebuf[off + e0 + 1 - c] : stagew[gl * 4 + 1];
+      q.z = e0 + 2 >= c ? tilebuf[off + e0 + 2 - c] : stagew[gl * 4 + 2];
+      q.w = tilebuf[off + j - c];
+      *(u32x4 *)(ent + dst[gl] + (int64_t)(j >> 2) * 256) = q;
     }
+    __syncthreads();
+
+    // ---- P5: per gene: open group -> carry, cur += n, mask cleared
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      int gl = ga + u;
+      uint32_t n = pre[gl] >> 24;
+      if (n) {
+        uint32_t c_o = co[gl], c = c_o & 0xFFFFu, off = c_o >> 16, nc = c + n;
+        uint32_t first = max(c, nc & ~3u);
+        for (uint32_t e = first; e < nc; e++) stagew[gl * 4 + (e & 3u)] = tilebuf[off + e - c];
+        co[gl] = nc;
+        mask[gl] = u32x4{0, 0, 0, 0};
+      }
+    }
+    if (tid == 0) *nfiled = 0;
+    __syncthreads();
+    r0 += T;
   }
-  // leftovers: the last, incomplete group of every gene of this wave (<= 3 entries; the rest of the group stays zero = padding)
-  for (int gl = lo + lane; gl < hi; gl += 64) {
-    uint32_t n = cur[gl];
-    for (uint32_t k = n & ~3u; k < n; k++) ent[dst[gl] + (int64_t)(k >> 2) * 256 + (k & 3)] = stage[gl * 4 + (k & 3)];
+  // leftovers: the last, incomplete group of every gene (<= 3 entries; the rest of the group is zero = padding)
+  for (int gl = tid; gl < ngr; gl += MR_THREADS) {
+    uint32_t n = co[gl] & 0xFFFFu, k = n & 3u;
+    if (k) {
+      u32x4 q = stage[gl];
+      if (k < 2) q.y = 0;
+      if (k < 3) q.z = 0;
+      q.w = 0;
+      *(u32x4 *)(ent + dst[gl] + (int64_t)(n >> 2) * 256) = q;
+    }
   }
   if (bad) atomicOr(status, 1);
 }
@@ -524,7 +645,7 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
 int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, int64_t n_sel, int32_t n_genes,
                   int32_t n_ranges, int64_t *d_rowsplit, int32_t *d_status, void *stream) {
   MM_ARG(d_indptr && d_indices && d_cell_order && d_rowsplit && d_status && n_sel >= 0 && n_genes > 0);
-  MM_ARG(n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
+  MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
   if (n_sel == 0) return MM_OK;
   int64_t blocks = (n_sel + 3) / 4;
   if (blocks > 16384) blocks = 16384;
@@ -540,37 +661,43 @@ int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, cons
   (void)d_indptr;
   (void)d_cell_order;   // the row positions come from d_rowsplit; kept in the signature next to mm_sell_count's
   MM_ARG(d_indices && d_blk_cell0 && d_rowsplit && d_blk_cnt);
-  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_genes <= 65536 && n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
+  MM_ARG(n_blocks >= 0 && n_genes > 0);
+  MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
   if (n_blocks == 0) return MM_OK;
-  size_t shm = (size_t)(n_genes / n_ranges + 1) * 4;
-  MM_ARG(shm <= 150 * 1024);
   int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
   MM_ARG(grid < 2147483647LL);
-  MM_HIP(hipFuncSetAttribute((const void *)k_sell_count_ranges, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(k_sell_count_ranges, dim3((unsigned)grid), dim3(1024), shm, (hipStream_t)stream, d_indices, d_blk_cell0, n_blocks,
+  hipLaunchKernelGGL(k_sell_count_ranges, dim3((unsigned)grid), dim3(1024), 0, (hipStream_t)stream, d_indices, d_blk_cell0, n_blocks,
                      n_genes, n_ranges, d_rowsplit, d_blk_cnt);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
 int mm_sell_scatter_ranges(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
-                           const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges,
+                           const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int32_t avg_segment,
                            const int64_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,
                            uint32_t *d_ent, int32_t *d_status, void *stream) {
   (void)d_indptr;
   (void)d_cell_order;
   MM_ARG(d_indices && d_data && d_blk_cell0 && d_rowsplit && d_rank && d_slice_ptr && d_blk_base && d_ent);
-  MM_ARG(d_status && n_blocks >= 0 && n_genes > 0 && n_genes <= 65536 && n_ranges >= 1 && n_ranges <= 32 && n_ranges <= n_genes);
+  MM_ARG(d_status && n_blocks >= 0 && n_genes > 0);
+  MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
   if (n_blocks == 0) return MM_OK;
   int32_t n_slices = (n_genes + 63) / 64;
-  int32_t ngr_max = n_genes / n_ranges + 1;
-  size_t shm = (size_t)ngr_max * (16 + 4 + 8) + 8;       // group buffer + cursor + destination per gene of the range
-  MM_ARG(shm <= 150 * 1024);
+  size_t shm = (size_t)MM_RANGE_GENES * (16 + 16 + 8 + 4 + 4) + (size_t)MR_EMAX * 5 + (MR_WAVES + 1) * 4;
   int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
   MM_ARG(grid < 2147483647LL);
-  MM_HIP(hipFuncSetAttribute((const void *)k_sell_scatter_quads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(k_sell_scatter_quads, dim3((unsigned)grid), dim3(64 * RS_WAVES), shm, (hipStream_t)stream, d_indices, d_data,
-                     d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_rank, d_slice_ptr, d_blk_base, d_ent, d_status);
+#define MR_LAUNCH(SUB)                                                                                                              \
+  do {                                                                                                                              \
+    MM_HIP(hipFuncSetAttribute((const void *)k_sell_scatter_tiles<SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));     \
+    hipLaunchKernelGGL(k_sell_scatter_tiles<SUB>, dim3((unsigned)grid), dim3(MR_THREADS), shm, (hipStream_t)stream, d_indices,     \
+                       d_data, d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_rank, d_slice_ptr, d_blk_base,    \
+                       d_ent, d_status);                                                                                            \
+  } while (0)
+  // lanes per row segment: the smallest of 16 / 32 / 64 that takes a typical segment in one instruction
+  if (avg_segment > 0 && avg_segment <= 12) MR_LAUNCH(16);
+  else if (avg_segment > 96) MR_LAUNCH(64);
+  else MR_LAUNCH(32);
+#undef MR_LAUNCH
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

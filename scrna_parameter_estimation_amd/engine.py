@@ -15,6 +15,7 @@ from . import _lib
 
 BLOCK_CELLS = 8192
 MAX_COUNT = (1 << 19) - 1
+RANGE_GENES, MAX_RANGES = 1024, 64   # include/memento_hip.h: MM_RANGE_GENES, MM_MAX_RANGES (range-partitioned ingest)
 ORDER_SMALL_CAP = 1024
 ORDER_BIG_CAP = 8192
 ORDER_BIG_CAP_2D = 4096
@@ -206,13 +207,14 @@ class CountBlocks:
         blk_cnt = zeros((nb, G), torch.int16)
         status = zeros((1,), torch.int32)
         bad_data = ValueError(f"count matrix must hold positive integer counts <= {MAX_COUNT} with valid column indices")
-        # Range-partitioned ingest (rows with ascending column indices: every canonical CSR): a workgroup owns (block, gene-id
-        # range), so a row contributes one contiguous segment and the block's open lines complete in one XCD's L2.  R ranges so
-        # that a (row, range) segment is about one wave wide.
+        # Range-partitioned ingest (rows with ascending column indices: every canonical CSR): a workgroup owns (block, range of
+        # 1024 consecutive gene ids), so a row contributes one contiguous segment to it and the per-gene state of the range lives
+        # in LDS (csrc/ingest.hip).
         n_sel = len(self.cell_order)
-        R = max(1, -(-int(csr.nnz) // (56 * max(1, csr.shape[0]))))      # ~one wave per (row, range) segment
-        R = max(R, -(-G // 5000))                                          # a range's per-gene state (28 B / gene) must fit the LDS
-        R = int(min(32, G, max(R, 1)))
+        R = -(-G // RANGE_GENES)
+        if R > MAX_RANGES:
+            raise ValueError(f"at most {MAX_RANGES * RANGE_GENES} genes per ingest")
+        avg_seg = int(csr.nnz) // max(1, int(csr.shape[0]) * R)
         rowsplit = empty((max(1, n_sel), R + 1), torch.int64)
         call("mm_sell_split", P(csr.indptr), P(csr.indices), P(self.d_cell_order), n_sel, G, R, P(rowsplit), P(status), s)
         self.ranged = (int(status.item()) & 2) == 0
@@ -245,7 +247,7 @@ class CountBlocks:
         self.ent = zeros((max(1, self.total_rows) * 256,), torch.int32)
         if self.ranged:
             call("mm_sell_scatter_ranges", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G, R,
-                 P(rowsplit), P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), P(status), s)
+                 avg_seg, P(rowsplit), P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), P(status), s)
             if int(status.item()) & 1:
                 raise bad_data
         else:
