@@ -252,19 +252,24 @@ __global__ __launch_bounds__(1024) void k_sell_scatter(const int64_t *__restrict
 //
 // Step 0: per row, where each gene range starts (R + 1 absolute positions in indices / data), and the structural checks
 // (column indices inside [0, G), strictly ascending).  One wave per row, coalesced index reads; a lane whose range id differs
-// from its predecessor's owns the boundaries in between (no ballots, no search); the row's R + 1 positions leave through LDS
-// as one coalesced store.
+// from its predecessor's owns the boundaries in between (no ballots, no search).  The table is stored [range][row], so that the
+// workgroup of (block, range) later reads its bounds as contiguous runs.
 __global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                     const int32_t *__restrict__ cell_order, int64_t n_sel, int32_t n_genes,
                                                     int32_t n_ranges, int64_t *__restrict__ rowsplit, int32_t *__restrict__ status) {
-  __shared__ volatile int64_t pos[4][MM_MAX_RANGES + 1];
+  // a workgroup takes 64 consecutive rows (16 per wave) and writes their table transposed: rowsplit[k][row], 512 B runs
+  __shared__ volatile int32_t pos[MM_MAX_RANGES + 1][64];    // offsets inside the row
+  __shared__ int64_t rstart[64];
   int lane = mm_lane(), wv = threadIdx.x >> 6;
-  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int64_t rbase = (int64_t)blockIdx.x * 64;
   int bad = 0;
-  for (int64_t r = wave; r < n_sel; r += nwaves) {
+  for (int u = 0; u < 16; u++) {
+    int rl = u * 4 + wv;
+    int64_t r = rbase + rl;
+    if (r >= n_sel) break;
     int cell = cell_order[r];
     int64_t s = indptr[cell], e = indptr[cell + 1];
+    if (lane == 0) rstart[rl] = s;
     int prev_g = -1, prev_key = -1;
     for (int64_t i0 = s; i0 <= e; i0 += 64) {       // position e takes part as the sentinel (range id R)
       int64_t i = i0 + lane;
@@ -284,20 +289,21 @@ __global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ 
       }
       if (i < e && g <= gp) bad = 1;                // not strictly ascending
       if (i <= e)
-        for (int k = kp + 1; k <= key; k++) pos[wv][k] = i;   // (an unsorted row may leave holes: it is flagged and not used)
+        for (int k = kp + 1; k <= key; k++) pos[k][rl] = (int32_t)(i - s);   // (an unsorted row may leave holes: flagged, not used)
       prev_g = __shfl(g, 63, 64);
       prev_key = __shfl(key, 63, 64);
     }
-    __builtin_amdgcn_wave_barrier();   // the same wave wrote and reads pos[wv]: its LDS operations complete in order
-    for (int k = lane; k <= n_ranges; k += 64) rowsplit[r * (n_ranges + 1) + k] = pos[wv][k];
-    __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();
+  int64_t r = rbase + lane;
+  if (r < n_sel)
+    for (int k = wv; k <= n_ranges; k += 4) rowsplit[(int64_t)k * n_sel + r] = rstart[lane] + pos[k][lane];
   if (bad) atomicOr(status, 2);
 }
 
 // Step 1: nnz per (block, gene).  One workgroup per (block, gene range); LDS counters of the range's genes only.
 __global__ __launch_bounds__(1024) void k_sell_count_ranges(const int32_t *__restrict__ indices, const int32_t *__restrict__ blk_cell0,
-                                                            int32_t n_blocks, int32_t n_genes, int32_t n_ranges,
+                                                            int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int64_t n_sel,
                                                             const int64_t *__restrict__ rowsplit, uint16_t *__restrict__ blk_cnt) {
   __shared__ uint32_t cur[MM_RANGE_GENES];               // counts of this range's genes
   // workgroup -> (block, range): the R workgroups of one block get ids that are equal mod 8, i.e. land on one XCD (speed only)
@@ -308,21 +314,21 @@ __global__ __launch_bounds__(1024) void k_sell_count_ranges(const int32_t *__res
   for (int i = threadIdx.x; i < ngr; i += blockDim.x) cur[i] = 0;
   __syncthreads();
   int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
-  const int64_t ld = n_ranges + 1;
+  const int64_t *rsA = rowsplit + (int64_t)rg * n_sel, *rsZ = rsA + n_sel;
   // a quarter wave per row segment; the NEXT row's segment bounds are fetched while the current one is processed
   int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
   int r = c0 + grp;
   int64_t a = 0, z = 0;
   if (r < c1) {
-    a = rowsplit[r * ld + rg];
-    z = rowsplit[r * ld + rg + 1];
+    a = rsA[r];
+    z = rsZ[r];
   }
   for (; r < c1; r += ngrp) {
     int rn = r + ngrp;
     int64_t an = 0, zn = 0;
     if (rn < c1) {
-      an = rowsplit[rn * ld + rg];
-      zn = rowsplit[rn * ld + rg + 1];
+      an = rsA[rn];
+      zn = rsZ[rn];
     }
     for (int64_t i = a + sub; i < z; i += 16) atomicAdd(&cur[indices[i] - g0], 1u);
     a = an;
@@ -347,11 +353,28 @@ __global__ __launch_bounds__(1024) void k_sell_count_ranges(const int32_t *__res
 //   P4  filed groups are read back (entries of earlier tiles from the gene's 4-slot carry) and stored, one dwordx4 each;
 //   P5  per gene: the open group moves to the carry, cur += n, mask cleared.
 // No entry is ever placed by arrival order: two ingests of one CSR give bit-identical count blocks, hence bit-identical fp64 sums.
+#ifdef INGEST_STAMPS
+__device__ unsigned long long g_ing[16];
+#define ING_ST(k)                                          \
+  do {                                                     \
+    unsigned long long n_ = __builtin_readcyclecounter();  \
+    st_acc[k] += n_ - st_last;                             \
+    st_last = n_;                                          \
+  } while (0)
+#else
+#define ING_ST(k)
+#endif
 #define MR_T 128          // rows per tile (= bits of the row mask)
-#define MR_EMAX 6144      // entries per tile (tile buffer)
+#define MR_EMAX 4096      // entries per tile (tile buffer)
 #define MR_THREADS 512
+// groups a tile can complete: per gene ceil(n / 4) <= n / 4 + 3 / 4, summed over the range's genes
+#define MR_FILED (MR_EMAX / 4 + MM_RANGE_GENES)
 #define MR_WAVES (MR_THREADS / 64)
 #define MR_WROWS (MR_T / MR_WAVES)   // 16 rows of a tile per wave
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads (vmcnt(0)),
+// which would end the software prefetch of the next tile at the first barrier.
+__device__ __forceinline__ void mm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int mm_wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -362,22 +385,24 @@ __device__ __forceinline__ int mm_wave_incl_scan(int v, int lane) {
   return v;
 }
 
-template <int SUB>   // lanes per row segment (16, 32 or 64): 64 / SUB rows are in flight per wave instruction
 __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int32_t *__restrict__ indices, const float *__restrict__ data,
-                                                                    const int32_t *__restrict__ blk_cell0, int32_t n_blocks,
-                                                                    int32_t n_genes, int32_t n_slices, int32_t n_ranges,
-                                                                    const int64_t *__restrict__ rowsplit, const int32_t *__restrict__ rank,
-                                                                    const int32_t *__restrict__ slice_ptr, const int64_t *__restrict__ blk_base,
-                                                                    uint32_t *__restrict__ ent, int32_t *__restrict__ status) {
+                                                                       const int32_t *__restrict__ blk_cell0, int32_t n_blocks,
+                                                                       int32_t n_genes, int32_t n_slices, int32_t n_ranges, int64_t n_sel,
+                                                                       const int64_t *__restrict__ rowsplit, const int32_t *__restrict__ rank,
+                                                                       const int32_t *__restrict__ slice_ptr, const int64_t *__restrict__ blk_base,
+                                                                       uint32_t *__restrict__ ent, int32_t *__restrict__ status) {
   extern __shared__ u32x4 smem_q[];
   u32x4 *mask = smem_q;                                        // [1024] row mask of the tile per gene
   u32x4 *stage = mask + MM_RANGE_GENES;                        // [1024] carry: the gene's open group (slot = position & 3)
-  int64_t *dst = (int64_t *)(stage + MM_RANGE_GENES);          // [1024] ent index of the gene's entry 0
-  uint32_t *pre = (uint32_t *)(dst + MM_RANGE_GENES);          // [1024] popcount prefixes of the mask words | n << 24
-  uint32_t *co = pre + MM_RANGE_GENES;                         // [1024] cur (entries placed before this tile) | run start << 16
-  uint32_t *tilebuf = co + MM_RANGE_GENES;                     // [MR_EMAX]
-  uint32_t *filed = tilebuf + MR_EMAX;                         // [MR_EMAX / 4] gene | position << 10 of every completed group
-  uint32_t *wtot = filed + MR_EMAX / 4;                        // [MR_WAVES] + [1] number of filed groups
+  uint2 *pc = (uint2 *)(stage + MM_RANGE_GENES);               // [1024] .x popcount prefixes of the mask words | n << 24
+                                                               //        .y cur (entries placed before this tile) | run start << 16
+  uint32_t *dst = (uint32_t *)(pc + MM_RANGE_GENES);           // [1024] (slice row of entry 0, relative to the block) << 6 | lane slot
+  int64_t *rowA = (int64_t *)(dst + MM_RANGE_GENES);           // [128] position of the row's segment in indices / data
+  int32_t *rowS = (int32_t *)(rowA + MR_T);                    // [128] entries of the tile before the row
+  uint32_t *tilebuf = (uint32_t *)(rowS + MR_T);               // [MR_EMAX]
+  uint32_t *filed = tilebuf + MR_EMAX;                         // [MR_FILED] gene | position << 10 of every completed group
+  uint8_t *rowOf = (uint8_t *)filed;                           //   (before P3: [MR_EMAX] row of every entry of the tile)
+  uint32_t *wtot = filed + MR_FILED;                        // [MR_WAVES] + [1] number of filed groups
   uint32_t *nfiled = wtot + MR_WAVES;
   uint32_t *maskw = (uint32_t *)mask;
   uint32_t *stagew = (uint32_t *)stage;
@@ -390,84 +415,121 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
   for (int i = tid; i < MM_RANGE_GENES; i += MR_THREADS) {
     mask[i] = u32x4{0, 0, 0, 0};
     stage[i] = u32x4{0, 0, 0, 0};
-    pre[i] = 0;
-    co[i] = 0;
-    int64_t d = 0;
+    pc[i] = uint2{0, 0};
+    uint32_t d = 0;
     if (i < ngr) {
       int sl = rank[(int64_t)b * n_genes + g0 + i];
-      d = (blk_base[b] + slice_ptr[(int64_t)b * (n_slices + 1) + (sl >> 6)]) * 256 + (sl & 63) * 4;
+      d = ((uint32_t)slice_ptr[(int64_t)b * (n_slices + 1) + (sl >> 6)] << 6) | (uint32_t)(sl & 63);
     }
     dst[i] = d;
   }
   if (tid == 0) *nfiled = 0;
   __syncthreads();
   const int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
-  const int64_t ld = n_ranges + 1;
-  constexpr int RPS = 64 / SUB;                 // rows per wave instruction
-  constexpr int ITER = MR_WROWS / RPS;
-  const int sl = lane & (SUB - 1), rsub = lane / SUB;
+  const int64_t base_row = blk_base[b];
+  const int64_t *rsA = rowsplit + (int64_t)rg * n_sel, *rsZ = rsA + n_sel;    // [range][row]: contiguous per workgroup
+  constexpr int KMAX = MR_EMAX / MR_THREADS;
   int bad = 0;
+#ifdef INGEST_STAMPS
+  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_tiles = 0;
+#endif
 
-  for (int r0 = c0; r0 < c1;) {
-    // ---- tile extent: every wave derives it from the same bounds (no exchange): lane L holds rows r0 + L and r0 + 64 + L
-    int64_t a0 = 0, a1 = 0;
-    int l0 = 0, l1 = 0;
-    if (r0 + lane < c1) {
-      a0 = rowsplit[(int64_t)(r0 + lane) * ld + rg];
-      l0 = (int)(rowsplit[(int64_t)(r0 + lane) * ld + rg + 1] - a0);
+  // Software pipeline over the tiles: while tile t is ranked and stored, the entries of tile t + 1 are already on their way
+  // (registers gr2 / en2) and the segment bounds of tile t + 2 as well.
+  // Segment bounds of a tile's rows: lane L holds rows r + L and r + 64 + L.
+  int64_t a0 = 0, z0 = 0, a1 = 0, z1 = 0;
+  auto load_bounds = [&](int r) {
+    a0 = z0 = a1 = z1 = 0;
+    if (r + lane < c1) {
+      a0 = rsA[r + lane];
+      z0 = rsZ[r + lane];
     }
-    if (r0 + 64 + lane < c1) {
-      a1 = rowsplit[(int64_t)(r0 + 64 + lane) * ld + rg];
-      l1 = (int)(rowsplit[(int64_t)(r0 + 64 + lane) * ld + rg + 1] - a1);
+    if (r + 64 + lane < c1) {
+      a1 = rsA[r + 64 + lane];
+      z1 = rsZ[r + 64 + lane];
     }
+  };
+  // from the bounds in (a0 .. z1) of the tile starting at row r: extent T and entries E (every wave derives the same values, no
+  // exchange), the row tables and the row of every entry in LDS (4 threads per row)
+  auto plan_tile = [&](int r, int &T, int &E) {
+    int l0 = (int)(z0 - a0), l1 = (int)(z1 - a1);
     int inc0 = mm_wave_incl_scan(l0, lane);
     int tot0 = __shfl(inc0, 63, 64);
     int inc1 = tot0 + mm_wave_incl_scan(l1, lane);
-    int T = __popcll(__ballot(inc0 <= MR_EMAX)) + __popcll(__ballot(inc1 <= MR_EMAX));   // cumulative counts are monotone
-    T = min(T, c1 - r0);                         // (>= 1: one segment holds at most 1024 entries)
-    // this wave's rows of the tile: wave * 16 .. + 16, all in the first or all in the second half
-    const int64_t srcA = wave < MR_WAVES / 2 ? a0 : a1;
-    const int srcL = wave < MR_WAVES / 2 ? l0 : l1;
-    const uint32_t cell_base = (uint32_t)(r0 - c0);
-
-    // ---- P1: row masks.  (The segment bounds are re-read from the holding lanes in every phase: three bpermutes are cheaper
-    // than 3 x ITER registers held across the barriers.)
-    int gi[ITER];
-    uint32_t en[ITER];
-    auto seg = [&](int row, int64_t &a, int &len) {
-      a = __shfl(srcA, row & 63, 64);
-      int L = __shfl(srcL, row & 63, 64);
-      len = row < T ? L : 0;
-    };
-#pragma unroll
-    for (int it = 0; it < ITER; it++) {
-      int row = wave * MR_WROWS + it * RPS + rsub, len;
-      int64_t a;
-      seg(row, a, len);
-      bool has = sl < len;
-      gi[it] = has ? indices[a + sl] : -1;
-      en[it] = has ? __float_as_uint(data[a + sl]) : 0u;
+    T = __popcll(__ballot(inc0 <= MR_EMAX)) + __popcll(__ballot(inc1 <= MR_EMAX));   // cumulative counts are monotone
+    T = min(T, c1 - r);                          // (>= 1 while r < c1: one segment holds at most 1024 entries)
+    E = 0;
+    if (T > 0) E = T <= 64 ? __shfl(inc0, (T - 1) & 63, 64) : __shfl(inc1, (T - 1) & 63, 64);
+    if (wave == 0 && lane < T) {
+      rowA[lane] = a0;
+      rowS[lane] = inc0 - l0;
     }
+    if (wave == 1 && 64 + lane < T) {
+      rowA[64 + lane] = a1;
+      rowS[64 + lane] = inc1 - l1;
+    }
+    int row = tid >> 2;                          // wave w covers rows 16 w .. 16 w + 15: all in one half
+    int st = __shfl(wave < MR_WAVES / 2 ? inc0 - l0 : inc1 - l1, row & 63, 64);
+    int ln = __shfl(wave < MR_WAVES / 2 ? l0 : l1, row & 63, 64);
+    if (row >= T) ln = 0;
+    for (int k = tid & 3; k < ln; k += 4) rowOf[st + k] = (uint8_t)row;
+  };
+  // thread -> entries tid, tid + 512, ... of the tile (coalesced along the rows).  In flight: raw column index, raw value and the
+  // row (a byte each, four per register); nothing is computed from a loaded value before the next pass, so the loads stay in
+  // flight behind the ranking and storing of the current tile.  After P1: gr = gene (10 bits) | row << 10, en = packed entry.
+  uint32_t gr[KMAX], en[KMAX], gi2[KMAX], en2[KMAX], rw[KMAX / 4], rw2[KMAX / 4];
+  auto issue_loads = [&](int E, uint32_t *pg, uint32_t *pe, uint32_t *pr) {
 #pragma unroll
-    for (int it = 0; it < ITER; it++) {
-      int row = wave * MR_WROWS + it * RPS + rsub, len;
-      int64_t a;
-      seg(row, a, len);
-      if (gi[it] >= 0) {
-        float v = __uint_as_float(en[it]);
+    for (int k = 0; k < KMAX / 4; k++) pr[k] = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      int e = tid + k * MR_THREADS;
+      int64_t pos = 0;                           // (entries past the tile's end read position 0: always valid memory, never used)
+      if (e < E) {
+        int row = rowOf[e];
+        pos = rowA[row] + (e - rowS[row]);
+        pr[k >> 2] |= (uint32_t)row << (8 * (k & 3));
+      }
+      pg[k] = (uint32_t)indices[pos];
+      pe[k] = __float_as_uint(data[pos]);
+    }
+  };
+  int r0 = c0, T = 0, E = 0;
+  load_bounds(r0);
+  plan_tile(r0, T, E);
+  load_bounds(r0 + T);                           // bounds of tile 1
+  __syncthreads();
+  issue_loads(E, gr, en, rw);
+  __syncthreads();                               // (the row tables are rewritten for tile 1 right away)
+  while (r0 < c1) {
+    ING_ST(9);
+    const uint32_t cell_base = (uint32_t)(r0 - c0);
+    // tile t + 1: extent and row tables (its bounds arrived during tile t - 1), then the bounds of tile t + 2
+    int rn = r0 + T, Tn = 0, En = 0;
+    plan_tile(rn, Tn, En);
+    load_bounds(rn + Tn);
+    ING_ST(0);
+    // ---- P1: row masks of tile t
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      uint32_t raw = gr[k];
+      gr[k] = ~0u;
+      if (tid + k * MR_THREADS < E) {
+        float v = __uint_as_float(en[k]);
         if (!(v >= 1.0f && v <= (float)MM_MAX_COUNT && v == floorf(v))) {   // counts: positive integers inside the 19-bit field
           bad = 1;
           v = 1.0f;
         }
-        int gl = gi[it] - g0;
-        gi[it] = gl;
-        en[it] = (cell_base + (uint32_t)row) | ((uint32_t)v << MM_CELL_BITS);
+        uint32_t gl = raw - (uint32_t)g0, row = (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        gr[k] = gl | (row << MM_RANGE_SHIFT);
+        en[k] = (cell_base + row) | ((uint32_t)v << MM_CELL_BITS);
         atomicOr(&maskw[gl * 4 + (row >> 5)], 1u << (row & 31));
       }
-      for (int k = sl + SUB; k < len; k += SUB)                              // the rest of a long segment
-        atomicOr(&maskw[(indices[a + k] - g0) * 4 + (row >> 5)], 1u << (row & 31));
     }
-    __syncthreads();
+    ING_ST(1);
+    mm_lds_barrier();
+    ING_ST(2);
+    issue_loads(En, gi2, en2, rw2);              // tile t + 1: in flight until the next pass
 
     // ---- P2: per gene (two per thread): prefixes of the mask popcounts, run starts by a workgroup-wide exclusive scan
     int ga = tid * 2;
@@ -476,86 +538,111 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
     uint32_t p1a = __popc(m1.x), p1b = p1a + __popc(m1.y), p1c = p1b + __popc(m1.z), n1 = p1c + __popc(m1.w);
     int incl = mm_wave_incl_scan((int)(n0 + n1), lane);
     if (lane == 63) wtot[wave] = (uint32_t)incl;
-    __syncthreads();
+    mm_lds_barrier();
     uint32_t before = 0;
 #pragma unroll
     for (int w = 0; w < MR_WAVES; w++) before += w < wave ? wtot[w] : 0;
     uint32_t off0 = before + (uint32_t)incl - n0 - n1, off1 = off0 + n0;
-    pre[ga] = p0a | (p0b << 8) | (p0c << 16) | (n0 << 24);
-    pre[ga + 1] = p1a | (p1b << 8) | (p1c << 16) | (n1 << 24);
-    co[ga] = (co[ga] & 0xFFFFu) | (off0 << 16);
-    co[ga + 1] = (co[ga + 1] & 0xFFFFu) | (off1 << 16);
-    __syncthreads();
+    pc[ga] = uint2{p0a | (p0b << 8) | (p0c << 16) | (n0 << 24), (pc[ga].y & 0xFFFFu) | (off0 << 16)};
+    pc[ga + 1] = uint2{p1a | (p1b << 8) | (p1c << 16) | (n1 << 24), (pc[ga + 1].y & 0xFFFFu) | (off1 << 16)};
+    mm_lds_barrier();
+    ING_ST(3);
 
     // ---- P3: place every entry of the tile in its gene's run; slot-3 entries file their group
-    auto place = [&](int gl, int row, uint32_t entry) {
-      uint32_t m = maskw[gl * 4 + (row >> 5)], p = pre[gl], c_o = co[gl];
-      uint32_t w = (uint32_t)row >> 5;
-      uint32_t below = w == 0 ? 0u : (p >> (8 * (w - 1))) & 0xFFu;
-      uint32_t rk = below + __popc(m & ((1u << (row & 31)) - 1u));
-      tilebuf[(c_o >> 16) + rk] = entry;
-      uint32_t j = (c_o & 0xFFFFu) + rk;
-      if ((j & 3u) == 3u) filed[atomicAdd(nfiled, 1u)] = (uint32_t)gl | (j << MM_RANGE_SHIFT);
-    };
 #pragma unroll
-    for (int it = 0; it < ITER; it++) {
-      int row = wave * MR_WROWS + it * RPS + rsub, len;
-      int64_t a;
-      seg(row, a, len);
-      if (gi[it] >= 0) place(gi[it], row, en[it]);
-      for (int k = sl + SUB; k < len; k += SUB) {
-        float v = data[a + k];
-        if (!(v >= 1.0f && v <= (float)MM_MAX_COUNT && v == floorf(v))) {
-          bad = 1;
-          v = 1.0f;
+    for (int k = 0; k < KMAX; k++) {
+      if (k * MR_THREADS < E) {                  // workgroup-uniform
+        uint32_t f = ~0u;
+        if (gr[k] != ~0u) {
+          uint32_t gl = gr[k] & (MM_RANGE_GENES - 1), row = gr[k] >> MM_RANGE_SHIFT, w = row >> 5;
+          uint32_t m = maskw[gl * 4 + w];
+          uint2 q = pc[gl];
+          uint32_t below = w == 0 ? 0u : (q.x >> (8 * (w - 1))) & 0xFFu;
+          uint32_t rk = below + __popc(m & ((1u << (row & 31)) - 1u));
+          tilebuf[(q.y >> 16) + rk] = en[k];
+          uint32_t j = (q.y & 0xFFFFu) + rk;
+          if ((j & 3u) == 3u) f = gl | (j << MM_RANGE_SHIFT);
         }
-        place(indices[a + k] - g0, row, (cell_base + (uint32_t)row) | ((uint32_t)v << MM_CELL_BITS));
+        uint64_t bal = __ballot(f != ~0u);       // one LDS atomic per wave for the groups this instruction completed
+        if (bal) {
+          int leader = __ffsll((long long)bal) - 1;
+          uint32_t base = 0;
+          if (lane == leader) base = atomicAdd(nfiled, (uint32_t)__popcll(bal));
+          base = __shfl(base, leader, 64);
+          if (f != ~0u) filed[base + __popcll(bal & ((1ull << lane) - 1ull))] = f;
+        }
       }
     }
-    __syncthreads();
+    ING_ST(4);
+    mm_lds_barrier();
+    ING_ST(5);
 
     // ---- P4: store the completed groups
     uint32_t nf = *nfiled;
     for (uint32_t k = tid; k < nf; k += MR_THREADS) {
       uint32_t f = filed[k];
       uint32_t gl = f & (MM_RANGE_GENES - 1), j = f >> MM_RANGE_SHIFT;          // j = position of the group's last entry
-      uint32_t c_o = co[gl], c = c_o & 0xFFFFu, off = c_o >> 16;
+      uint32_t c_o = pc[gl].y, c = c_o & 0xFFFFu, off = c_o >> 16;
       uint32_t e0 = j - 3u;
       u32x4 q;
       q.x = e0 >= c ? tilebuf[off + e0 - c] : stagew[gl * 4 + 0];
       q.y = e0 + 1 >= c ? tilebuf[off + e0 + 1 - c] : stagew[gl * 4 + 1];
       q.z = e0 + 2 >= c ? tilebuf[off + e0 + 2 - c] : stagew[gl * 4 + 2];
       q.w = tilebuf[off + j - c];
-      *(u32x4 *)(ent + dst[gl] + (int64_t)(j >> 2) * 256) = q;
+      uint32_t d = dst[gl];
+      *(u32x4 *)(ent + (base_row + (d >> 6) + (j >> 2)) * 256 + (d & 63u) * 4) = q;
     }
-    __syncthreads();
+    ING_ST(6);
+    mm_lds_barrier();
+    ING_ST(7);
 
     // ---- P5: per gene: open group -> carry, cur += n, mask cleared
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       int gl = ga + u;
-      uint32_t n = pre[gl] >> 24;
+      uint2 q = pc[gl];
+      uint32_t n = q.x >> 24;
       if (n) {
-        uint32_t c_o = co[gl], c = c_o & 0xFFFFu, off = c_o >> 16, nc = c + n;
+        uint32_t c = q.y & 0xFFFFu, off = q.y >> 16, nc = c + n;
         uint32_t first = max(c, nc & ~3u);
         for (uint32_t e = first; e < nc; e++) stagew[gl * 4 + (e & 3u)] = tilebuf[off + e - c];
-        co[gl] = nc;
+        pc[gl].y = nc;
         mask[gl] = u32x4{0, 0, 0, 0};
       }
     }
     if (tid == 0) *nfiled = 0;
-    __syncthreads();
-    r0 += T;
+    mm_lds_barrier();
+    ING_ST(8);
+    r0 = rn;
+    T = Tn;
+    E = En;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      gr[k] = gi2[k];
+      en[k] = en2[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX / 4; k++) rw[k] = rw2[k];
+#ifdef INGEST_STAMPS
+    st_tiles++;
+#endif
   }
+#ifdef INGEST_STAMPS
+  if (lane == 0) {
+    for (int k = 0; k < 10; k++) atomicAdd(&g_ing[k], st_acc[k]);
+    atomicAdd(&g_ing[10], st_tiles);
+  }
+#endif
   // leftovers: the last, incomplete group of every gene (<= 3 entries; the rest of the group is zero = padding)
   for (int gl = tid; gl < ngr; gl += MR_THREADS) {
-    uint32_t n = co[gl] & 0xFFFFu, k = n & 3u;
+    uint32_t n = pc[gl].y & 0xFFFFu, k = n & 3u;
     if (k) {
       u32x4 q = stage[gl];
       if (k < 2) q.y = 0;
       if (k < 3) q.z = 0;
       q.w = 0;
-      *(u32x4 *)(ent + dst[gl] + (int64_t)(n >> 2) * 256) = q;
+      uint32_t d = dst[gl];
+      *(u32x4 *)(ent + (base_row + (d >> 6) + (n >> 2)) * 256 + (d & 63u) * 4) = q;
     }
   }
   if (bad) atomicOr(status, 1);
@@ -647,8 +734,8 @@ int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32
   MM_ARG(d_indptr && d_indices && d_cell_order && d_rowsplit && d_status && n_sel >= 0 && n_genes > 0);
   MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
   if (n_sel == 0) return MM_OK;
-  int64_t blocks = (n_sel + 3) / 4;
-  if (blocks > 16384) blocks = 16384;
+  int64_t blocks = (n_sel + 63) / 64;
+  MM_ARG(blocks < 2147483647LL);
   hipLaunchKernelGGL(k_sell_split, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_cell_order, n_sel,
                      n_genes, n_ranges, d_rowsplit, d_status);
   MM_LAUNCH_CHECK();
@@ -656,50 +743,54 @@ int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32
 }
 
 int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
-                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, const int64_t *d_rowsplit, uint16_t *d_blk_cnt,
-                         void *stream) {
+                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int64_t n_sel, const int64_t *d_rowsplit,
+                         uint16_t *d_blk_cnt, void *stream) {
   (void)d_indptr;
   (void)d_cell_order;   // the row positions come from d_rowsplit; kept in the signature next to mm_sell_count's
   MM_ARG(d_indices && d_blk_cell0 && d_rowsplit && d_blk_cnt);
-  MM_ARG(n_blocks >= 0 && n_genes > 0);
+  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_sel >= 0);
   MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
   if (n_blocks == 0) return MM_OK;
   int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
   MM_ARG(grid < 2147483647LL);
   hipLaunchKernelGGL(k_sell_count_ranges, dim3((unsigned)grid), dim3(1024), 0, (hipStream_t)stream, d_indices, d_blk_cell0, n_blocks,
-                     n_genes, n_ranges, d_rowsplit, d_blk_cnt);
+                     n_genes, n_ranges, n_sel, d_rowsplit, d_blk_cnt);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
 int mm_sell_scatter_ranges(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
-                           const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int32_t avg_segment,
+                           const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int64_t n_sel,
                            const int64_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,
                            uint32_t *d_ent, int32_t *d_status, void *stream) {
   (void)d_indptr;
   (void)d_cell_order;
   MM_ARG(d_indices && d_data && d_blk_cell0 && d_rowsplit && d_rank && d_slice_ptr && d_blk_base && d_ent);
-  MM_ARG(d_status && n_blocks >= 0 && n_genes > 0);
+  MM_ARG(d_status && n_blocks >= 0 && n_genes > 0 && n_sel >= 0);
   MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
   if (n_blocks == 0) return MM_OK;
   int32_t n_slices = (n_genes + 63) / 64;
-  size_t shm = (size_t)MM_RANGE_GENES * (16 + 16 + 8 + 4 + 4) + (size_t)MR_EMAX * 5 + (MR_WAVES + 1) * 4;
+  size_t shm = (size_t)MM_RANGE_GENES * (16 + 16 + 8 + 4) + (size_t)MR_T * 12 + (size_t)MR_EMAX * 4 + (size_t)MR_FILED * 4 + (MR_WAVES + 1) * 4;
   int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
   MM_ARG(grid < 2147483647LL);
-#define MR_LAUNCH(SUB)                                                                                                              \
-  do {                                                                                                                              \
-    MM_HIP(hipFuncSetAttribute((const void *)k_sell_scatter_tiles<SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));     \
-    hipLaunchKernelGGL(k_sell_scatter_tiles<SUB>, dim3((unsigned)grid), dim3(MR_THREADS), shm, (hipStream_t)stream, d_indices,     \
-                       d_data, d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, d_rowsplit, d_rank, d_slice_ptr, d_blk_base,    \
-                       d_ent, d_status);                                                                                            \
-  } while (0)
-  // lanes per row segment: the smallest of 16 / 32 / 64 that takes a typical segment in one instruction
-  if (avg_segment > 0 && avg_segment <= 12) MR_LAUNCH(16);
-  else if (avg_segment > 96) MR_LAUNCH(64);
-  else MR_LAUNCH(32);
-#undef MR_LAUNCH
+  MM_HIP(hipFuncSetAttribute((const void *)k_sell_scatter_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_sell_scatter_tiles, dim3((unsigned)grid), dim3(MR_THREADS), shm, (hipStream_t)stream, d_indices, d_data,
+                     d_blk_cell0, n_blocks, n_genes, n_slices, n_ranges, n_sel, d_rowsplit, d_rank, d_slice_ptr, d_blk_base, d_ent,
+                     d_status);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
+
+#ifdef INGEST_STAMPS
+int mm_debug_ingest_stamps(unsigned long long *host_out16, int reset) {
+  MM_HIP(hipDeviceSynchronize());
+  if (host_out16) MM_HIP(hipMemcpyFromSymbol(host_out16, HIP_SYMBOL(g_ing), 16 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    MM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ing), z, sizeof(z)));
+  }
+  return MM_OK;
+}
+#endif
 
 }  // extern "C"

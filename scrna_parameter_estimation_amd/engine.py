@@ -214,13 +214,12 @@ class CountBlocks:
         R = -(-G // RANGE_GENES)
         if R > MAX_RANGES:
             raise ValueError(f"at most {MAX_RANGES * RANGE_GENES} genes per ingest")
-        avg_seg = int(csr.nnz) // max(1, int(csr.shape[0]) * R)
-        rowsplit = empty((max(1, n_sel), R + 1), torch.int64)
+        rowsplit = empty((R + 1, max(1, n_sel)), torch.int64)     # [range][row]
         call("mm_sell_split", P(csr.indptr), P(csr.indices), P(self.d_cell_order), n_sel, G, R, P(rowsplit), P(status), s)
         self.ranged = (int(status.item()) & 2) == 0
         if self.ranged:
             call("mm_sell_count_ranges", P(csr.indptr), P(csr.indices), P(self.d_cell_order), P(self.d_blk_cell0), nb, G, R,
-                 P(rowsplit), P(blk_cnt), s)
+                 n_sel, P(rowsplit), P(blk_cnt), s)
         else:       # unsorted rows (or column indices out of range: reported by the count kernel): the unpartitioned kernels
             status.zero_()
             call("mm_sell_count", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
@@ -247,7 +246,7 @@ class CountBlocks:
         self.ent = zeros((max(1, self.total_rows) * 256,), torch.int32)
         if self.ranged:
             call("mm_sell_scatter_ranges", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G, R,
-                 avg_seg, P(rowsplit), P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), P(status), s)
+                 n_sel, P(rowsplit), P(self.rank), P(self.slice_ptr), P(self.blk_base), P(self.ent), P(status), s)
             if int(status.item()) & 1:
                 raise bad_data
         else:
