@@ -273,7 +273,7 @@ def main():
         nnz = int(state.csr.nnz)
         csr_bytes = nnz * 8 + (N + 1) * 4 + N * 8 + n_groups * G * 5 * 8
         t_ms = k0_ms + k1_ms
-        roof_csr = {"kernels": "K0 ingest, once per grouping (k_sell_split + k_sell_ranges<count> + k_sell_layout + k_sell_ranges<scatter>) + k_moments1d_sell", "bound": "hbm",
+        roof_csr = {"kernels": "K0 ingest, once per grouping (k_sell_split + k_sell_count_ranges + k_sell_layout + k_sell_scatter_tiles) + k_moments1d_sell", "bound": "hbm",
                     "achieved": round(csr_bytes / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(csr_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "bytes": int(csr_bytes),
                     "ms": round(t_ms, 3), "ms_parts": dict({k: round(v, 3) for k, v in k0.items()}, mm_moments1d_sell=round(k1_ms, 4)),

@@ -366,7 +366,11 @@ __device__ unsigned long long g_ing[16];
 #endif
 #define MR_T 128          // rows per tile (= bits of the row mask)
 #define MR_EMAX 4096      // entries per tile (tile buffer)
+#ifndef MR_THREADS
 #define MR_THREADS 512
+#endif
+#define MR_GPT (MM_RANGE_GENES / MR_THREADS)   // genes per thread in the per-gene phases
+#define MR_TPR (MR_THREADS / MR_T)            // threads per row when the row of every entry is written out
 // groups a tile can complete: per gene ceil(n / 4) <= n / 4 + 3 / 4, summed over the range's genes
 #define MR_FILED (MR_EMAX / 4 + MM_RANGE_GENES)
 #define MR_WAVES (MR_THREADS / 64)
@@ -376,16 +380,19 @@ __device__ unsigned long long g_ing[16];
 // which would end the software prefetch of the next tile at the first barrier.
 __device__ __forceinline__ void mm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ int mm_wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
-  }
+// Inclusive scan over the 64 lanes in the VALU's DPP network (no LDS crossbar): row_shr 1, 2, 4, 8 inside every row of 16,
+// then row_bcast:15 / row_bcast:31 carry the row totals over.  All 64 lanes must be active.
+__device__ __forceinline__ int mm_wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // lane 15 of rows 0 / 2 -> rows 1 / 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // lane 31 -> rows 2 and 3
   return v;
 }
 
-__global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int32_t *__restrict__ indices, const float *__restrict__ data,
+__global__ __launch_bounds__(MR_THREADS, MR_THREADS / 128) void k_sell_scatter_tiles(const int32_t *__restrict__ indices, const float *__restrict__ data,
                                                                        const int32_t *__restrict__ blk_cell0, int32_t n_blocks,
                                                                        int32_t n_genes, int32_t n_slices, int32_t n_ranges, int64_t n_sel,
                                                                        const int64_t *__restrict__ rowsplit, const int32_t *__restrict__ rank,
@@ -431,35 +438,34 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
   constexpr int KMAX = MR_EMAX / MR_THREADS;
   int bad = 0;
 #ifdef INGEST_STAMPS
-  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_tiles = 0;
+  unsigned long long st_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_tiles = 0;
 #endif
 
   // Software pipeline over the tiles: while tile t is ranked and stored, the entries of tile t + 1 are already on their way
   // (registers gr2 / en2) and the segment bounds of tile t + 2 as well.
   // Segment bounds of a tile's rows: lane L holds rows r + L and r + 64 + L.
-  int64_t a0 = 0, z0 = 0, a1 = 0, z1 = 0;
+  int64_t a0 = 0, a1 = 0;
+  uint32_t z0 = 0, z1 = 0;                        // low halves of the segment ends (only end - start is used)
+  // (rows past the block's end read its last row -- valid memory -- and count as empty in plan_tile: a conditional load would
+  // put a use of the loaded value, hence a wait, right behind the load)
   auto load_bounds = [&](int r) {
-    a0 = z0 = a1 = z1 = 0;
-    if (r + lane < c1) {
-      a0 = rsA[r + lane];
-      z0 = rsZ[r + lane];
-    }
-    if (r + 64 + lane < c1) {
-      a1 = rsA[r + 64 + lane];
-      z1 = rsZ[r + 64 + lane];
-    }
+    int ra = min(r + lane, c1 - 1), rb = min(r + 64 + lane, c1 - 1);
+    a0 = rsA[ra];
+    z0 = ((const uint32_t *)rsZ)[2 * ra];        // (a full 8-byte load would leave a dead high register that the allocator
+    a1 = rsA[rb];                                //  reuses at once -- a write-after-write wait on the load in flight)
+    z1 = ((const uint32_t *)rsZ)[2 * rb];
   };
   // from the bounds in (a0 .. z1) of the tile starting at row r: extent T and entries E (every wave derives the same values, no
   // exchange), the row tables and the row of every entry in LDS (4 threads per row)
   auto plan_tile = [&](int r, int &T, int &E) {
-    int l0 = (int)(z0 - a0), l1 = (int)(z1 - a1);
-    int inc0 = mm_wave_incl_scan(l0, lane);
-    int tot0 = __shfl(inc0, 63, 64);
-    int inc1 = tot0 + mm_wave_incl_scan(l1, lane);
+    int l0 = r + lane < c1 ? (int)(z0 - (uint32_t)a0) : 0, l1 = r + 64 + lane < c1 ? (int)(z1 - (uint32_t)a1) : 0;
+    int inc0 = mm_wave_incl_scan(l0);
+    int tot0 = __builtin_amdgcn_readlane(inc0, 63);
+    int inc1 = tot0 + mm_wave_incl_scan(l1);
     T = __popcll(__ballot(inc0 <= MR_EMAX)) + __popcll(__ballot(inc1 <= MR_EMAX));   // cumulative counts are monotone
     T = min(T, c1 - r);                          // (>= 1 while r < c1: one segment holds at most 1024 entries)
     E = 0;
-    if (T > 0) E = T <= 64 ? __shfl(inc0, (T - 1) & 63, 64) : __shfl(inc1, (T - 1) & 63, 64);
+    if (T > 0) E = T <= 64 ? __builtin_amdgcn_readlane(inc0, (T - 1) & 63) : __builtin_amdgcn_readlane(inc1, (T - 1) & 63);
     if (wave == 0 && lane < T) {
       rowA[lane] = a0;
       rowS[lane] = inc0 - l0;
@@ -468,11 +474,11 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
       rowA[64 + lane] = a1;
       rowS[64 + lane] = inc1 - l1;
     }
-    int row = tid >> 2;                          // wave w covers rows 16 w .. 16 w + 15: all in one half
+    int row = tid / MR_TPR;                      // the rows of one wave lie all in the first or all in the second half
     int st = __shfl(wave < MR_WAVES / 2 ? inc0 - l0 : inc1 - l1, row & 63, 64);
     int ln = __shfl(wave < MR_WAVES / 2 ? l0 : l1, row & 63, 64);
     if (row >= T) ln = 0;
-    for (int k = tid & 3; k < ln; k += 4) rowOf[st + k] = (uint8_t)row;
+    for (int k = tid % MR_TPR; k < ln; k += MR_TPR) rowOf[st + k] = (uint8_t)row;
   };
   // thread -> entries tid, tid + 512, ... of the tile (coalesced along the rows).  In flight: raw column index, raw value and the
   // row (a byte each, four per register); nothing is computed from a loaded value before the next pass, so the loads stay in
@@ -481,15 +487,17 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
   auto issue_loads = [&](int E, uint32_t *pg, uint32_t *pe, uint32_t *pr) {
 #pragma unroll
     for (int k = 0; k < KMAX / 4; k++) pr[k] = 0;
+    const int elast = max(E - 1, 0);
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
       int e = tid + k * MR_THREADS;
-      int64_t pos = 0;                           // (entries past the tile's end read position 0: always valid memory, never used)
-      if (e < E) {
-        int row = rowOf[e];
-        pos = rowA[row] + (e - rowS[row]);
-        pr[k >> 2] |= (uint32_t)row << (8 * (k & 3));
+      int row = rowOf[min(e, elast)] & (MR_T - 1);          // branch-free: LDS reads stay inside their arrays
+      int64_t pos = rowA[row] + (e - rowS[row]);
+      if (e >= E) {                              // entries past the tile's end read position 0: valid memory, never used
+        pos = 0;
+        row = 0;
       }
+      pr[k >> 2] |= (uint32_t)row << (8 * (k & 3));
       pg[k] = (uint32_t)indices[pos];
       pe[k] = __float_as_uint(data[pos]);
     }
@@ -497,17 +505,16 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
   int r0 = c0, T = 0, E = 0;
   load_bounds(r0);
   plan_tile(r0, T, E);
-  load_bounds(r0 + T);                           // bounds of tile 1
   __syncthreads();
   issue_loads(E, gr, en, rw);
+  load_bounds(r0 + T);                           // bounds of tile 1
   __syncthreads();                               // (the row tables are rewritten for tile 1 right away)
   while (r0 < c1) {
     ING_ST(9);
     const uint32_t cell_base = (uint32_t)(r0 - c0);
-    // tile t + 1: extent and row tables (its bounds arrived during tile t - 1), then the bounds of tile t + 2
+    // tile t + 1: extent and row tables (its bounds arrived during tile t - 1)
     int rn = r0 + T, Tn = 0, En = 0;
     plan_tile(rn, Tn, En);
-    load_bounds(rn + Tn);
     ING_ST(0);
     // ---- P1: row masks of tile t
 #pragma unroll
@@ -529,48 +536,69 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
     ING_ST(1);
     mm_lds_barrier();
     ING_ST(2);
-    issue_loads(En, gi2, en2, rw2);              // tile t + 1: in flight until the next pass
+    issue_loads(En, gi2, en2, rw2);              // tile t + 1: in flight until the next pass,
+    load_bounds(rn + Tn);                        // and the bounds of tile t + 2 behind them (the counter of outstanding loads
+                                                 // retires in order: the youngest loads must be the ones needed last)
+    ING_ST(10);
 
-    // ---- P2: per gene (two per thread): prefixes of the mask popcounts, run starts by a workgroup-wide exclusive scan
-    int ga = tid * 2;
-    u32x4 m0 = mask[ga], m1 = mask[ga + 1];
-    uint32_t p0a = __popc(m0.x), p0b = p0a + __popc(m0.y), p0c = p0b + __popc(m0.z), n0 = p0c + __popc(m0.w);
-    uint32_t p1a = __popc(m1.x), p1b = p1a + __popc(m1.y), p1c = p1b + __popc(m1.z), n1 = p1c + __popc(m1.w);
-    int incl = mm_wave_incl_scan((int)(n0 + n1), lane);
-    if (lane == 63) wtot[wave] = (uint32_t)incl;
-    mm_lds_barrier();
-    uint32_t before = 0;
+    // ---- P2: per gene: prefixes of the mask popcounts, run starts by a workgroup-wide exclusive scan
+    const int ga = tid * MR_GPT;
+    uint32_t pp[MR_GPT], nn[MR_GPT], nsum = 0;
 #pragma unroll
-    for (int w = 0; w < MR_WAVES; w++) before += w < wave ? wtot[w] : 0;
-    uint32_t off0 = before + (uint32_t)incl - n0 - n1, off1 = off0 + n0;
-    pc[ga] = uint2{p0a | (p0b << 8) | (p0c << 16) | (n0 << 24), (pc[ga].y & 0xFFFFu) | (off0 << 16)};
-    pc[ga + 1] = uint2{p1a | (p1b << 8) | (p1c << 16) | (n1 << 24), (pc[ga + 1].y & 0xFFFFu) | (off1 << 16)};
+    for (int u = 0; u < MR_GPT; u++) {
+      u32x4 m = mask[ga + u];
+      uint32_t pa = __popc(m.x), pb = pa + __popc(m.y), pcn = pb + __popc(m.z);
+      nn[u] = pcn + __popc(m.w);
+      pp[u] = pa | (pb << 8) | (pcn << 16) | (nn[u] << 24);
+      nsum += nn[u];
+    }
+    int incl = mm_wave_incl_scan((int)nsum);
+    if (lane == 63) wtot[wave] = (uint32_t)incl;
+    ING_ST(11);
+    mm_lds_barrier();
+    ING_ST(12);
+    uint32_t off = 0;
+#pragma unroll
+    for (int w = 0; w < MR_WAVES; w++) off += w < wave ? wtot[w] : 0;
+    off += (uint32_t)incl - nsum;
+#pragma unroll
+    for (int u = 0; u < MR_GPT; u++) {
+      pc[ga + u] = uint2{pp[u], (pc[ga + u].y & 0xFFFFu) | (off << 16)};
+      off += nn[u];
+    }
     mm_lds_barrier();
     ING_ST(3);
 
-    // ---- P3: place every entry of the tile in its gene's run; slot-3 entries file their group
+    // ---- P3: place every entry of the tile in its gene's run; slot-3 entries file their group (one LDS atomic per wave and tile)
+    uint32_t fl[KMAX];
+    uint32_t nmine = 0;
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
-      if (k * MR_THREADS < E) {                  // workgroup-uniform
-        uint32_t f = ~0u;
-        if (gr[k] != ~0u) {
-          uint32_t gl = gr[k] & (MM_RANGE_GENES - 1), row = gr[k] >> MM_RANGE_SHIFT, w = row >> 5;
-          uint32_t m = maskw[gl * 4 + w];
-          uint2 q = pc[gl];
-          uint32_t below = w == 0 ? 0u : (q.x >> (8 * (w - 1))) & 0xFFu;
-          uint32_t rk = below + __popc(m & ((1u << (row & 31)) - 1u));
-          tilebuf[(q.y >> 16) + rk] = en[k];
-          uint32_t j = (q.y & 0xFFFFu) + rk;
-          if ((j & 3u) == 3u) f = gl | (j << MM_RANGE_SHIFT);
+      fl[k] = ~0u;
+      if (gr[k] != ~0u) {
+        uint32_t gl = gr[k] & (MM_RANGE_GENES - 1), row = gr[k] >> MM_RANGE_SHIFT, w = row >> 5;
+        uint32_t m = maskw[gl * 4 + w];
+        uint2 q = pc[gl];
+        uint32_t below = w == 0 ? 0u : (q.x >> (8 * (w - 1))) & 0xFFu;
+        uint32_t rk = below + __popc(m & ((1u << (row & 31)) - 1u));
+        tilebuf[(q.y >> 16) + rk] = en[k];
+        uint32_t j = (q.y & 0xFFFFu) + rk;
+        if ((j & 3u) == 3u) {
+          fl[k] = gl | (j << MM_RANGE_SHIFT);
+          nmine++;
         }
-        uint64_t bal = __ballot(f != ~0u);       // one LDS atomic per wave for the groups this instruction completed
-        if (bal) {
-          int leader = __ffsll((long long)bal) - 1;
-          uint32_t base = 0;
-          if (lane == leader) base = atomicAdd(nfiled, (uint32_t)__popcll(bal));
-          base = __shfl(base, leader, 64);
-          if (f != ~0u) filed[base + __popcll(bal & ((1ull << lane) - 1ull))] = f;
-        }
+      }
+    }
+    {
+      int incl_f = mm_wave_incl_scan((int)nmine);
+      int tot_f = __builtin_amdgcn_readlane(incl_f, 63);
+      uint32_t base = 0;
+      if (tot_f) {
+        if (lane == 0) base = atomicAdd(nfiled, (uint32_t)tot_f);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + (uint32_t)incl_f - nmine;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+          if (fl[k] != ~0u) filed[base++] = fl[k];
       }
     }
     ING_ST(4);
@@ -598,7 +626,7 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
 
     // ---- P5: per gene: open group -> carry, cur += n, mask cleared
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < MR_GPT; u++) {
       int gl = ga + u;
       uint2 q = pc[gl];
       uint32_t n = q.x >> 24;
@@ -629,7 +657,7 @@ __global__ __launch_bounds__(MR_THREADS, 2) void k_sell_scatter_tiles(const int3
   }
 #ifdef INGEST_STAMPS
   if (lane == 0) {
-    for (int k = 0; k < 10; k++) atomicAdd(&g_ing[k], st_acc[k]);
+    for (int k = 0; k < 13; k++) atomicAdd(&g_ing[k < 10 ? k : k + 1], st_acc[k]);
     atomicAdd(&g_ing[10], st_tiles);
   }
 #endif

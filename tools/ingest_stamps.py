@@ -19,7 +19,8 @@ for rd in range(2):
     f(out, 0)
     v = np.array(list(out), dtype=np.float64)
     tiles = v[10]          # wave-tiles
-    names = ["bounds+T", "P1 loads+masks", "barrier1", "P2 scan", "P3 place", "barrier3", "P4 store", "barrier4", "P5+barrier", "loop"]
+    names = ["bounds+T", "P1 loads+masks", "barrier1", "P2 rest", "P3 place", "barrier3", "P4 store", "barrier4", "P5+barrier", "loop"]
     print({k: round(x, 3) for k, x in t.items()})
-    print("wave-tiles", int(tiles), "cycles per wave-tile:", {n: int(v[i] / tiles) for i, n in enumerate(names)}, "sum", int(v[:10].sum() / tiles))
+    extra = {"issue next loads": int(v[11] / tiles), "P2 popcounts+scan": int(v[12] / tiles), "barrier2": int(v[13] / tiles)}
+    print("wave-tiles", int(tiles), "cycles per wave-tile:", {n: int(v[i] / tiles) for i, n in enumerate(names)}, extra, "sum", int((v[:10].sum() + v[11:14].sum()) / tiles))
     del blocks
