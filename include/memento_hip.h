@@ -99,10 +99,13 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
 /* Range-partitioned form of steps 1 and 3 for rows with strictly ascending column indices (canonical CSR): the path the
  * Python driver takes; mm_sell_count / mm_sell_scatter above remain for unsorted rows.  The gene ids are cut into
  * n_ranges = ceil(G / MM_RANGE_GENES) ranges of MM_RANGE_GENES = 1024 consecutive ids (G <= 65536).
- * mm_sell_split: d_rowsplit[k][r], k = 0..R = absolute position in d_indices / d_data at which range k begins in selected row r
- * (block order, n_sel rows; range-major so that a (block, range) workgroup reads contiguous runs); d_status |= 2 if some row is not strictly ascending or has a column outside [0, G).
- * mm_sell_count_ranges fills d_blk_cnt like mm_sell_count (without the value check); mm_sell_scatter_ranges places the entries
- * in the layout of mm_sell_scatter and validates the values (d_status |= 1: not a positive integer count <= MM_MAX_COUNT);
+ * mm_sell_split_count, one pass over the column indices: d_rowsplit[k][r], k = 0..R = absolute position in d_indices / d_data at
+ * which range k begins in selected row r (block order, n_sel rows; range-major so that a (block, range) workgroup reads contiguous
+ * runs); d_status |= 2 if some row is not strictly ascending or has a column outside [0, G); and d_blk_cnt as mm_sell_count fills
+ * it, without the value check (d_blk_cnt must be ZERO-FILLED, 4-byte aligned and hold an even number of uint16: partial counts
+ * are merged by 32-bit atomics).
+ * mm_sell_scatter_ranges places the entries in the layout of mm_sell_scatter and validates the values (d_status |= 1: not a
+ * positive integer count <= MM_MAX_COUNT); d_indices / d_data need no alignment beyond their element size.
  * One workgroup per (block, range).  Stores are written through on this chip -- a lone 4-byte store costs ~26 B of HBM write
  * traffic (measured: the unpartitioned scatter writes 7.8x its algorithmic bytes, profiles/r02_k1_traffic_C3.json) -- so the
  * scatter assembles entries in LDS, tile of <= 128 rows by tile, and stores only complete 16-byte groups (4 consecutive entries
@@ -111,11 +114,10 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
 #define MM_RANGE_SHIFT 10
 #define MM_RANGE_GENES (1 << MM_RANGE_SHIFT)
 #define MM_MAX_RANGES 64
-int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, int64_t n_sel, int32_t n_genes,
-                  int32_t n_ranges, int64_t *d_rowsplit /* [n_ranges+1][n_sel] */, int32_t *d_status, void *stream);
-int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
-                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int64_t n_sel, const int64_t *d_rowsplit,
-                         uint16_t *d_blk_cnt, void *stream);
+int mm_sell_split_count(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
+                        int32_t n_blocks, int64_t n_sel, int32_t n_genes, int32_t n_ranges,
+                        int64_t *d_rowsplit /* [n_ranges+1][n_sel] */, uint16_t *d_blk_cnt /* [nb][G], zero-filled */,
+                        int32_t *d_status, void *stream);
 int mm_sell_scatter_ranges(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, const int32_t *d_cell_order,
                            const int32_t *d_blk_cell0, int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int64_t n_sel,
                            const int64_t *d_rowsplit, const int32_t *d_rank, const int32_t *d_slice_ptr, const int64_t *d_blk_base,

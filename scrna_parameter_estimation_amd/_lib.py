@@ -45,8 +45,7 @@ _SIGS = {
     "mm_sell_count": ([c_void_p] * 5 + [c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_sell_layout": ([c_void_p, c_int32, c_int32] + [c_void_p] * 8, ctypes.c_int),
     "mm_sell_scatter": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 5, ctypes.c_int),
-    "mm_sell_split": ([c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "mm_sell_count_ranges": ([c_void_p] * 4 + [c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_sell_split_count": ([c_void_p] * 4 + [c_int32, c_int64, c_int32, c_int32] + [c_void_p] * 4, ctypes.c_int),
     "mm_sell_scatter_ranges": ([c_void_p] * 5 + [c_int32, c_int32, c_int32, c_int64] + [c_void_p] * 7, ctypes.c_int),
     "mm_moments1d_sell": ([c_void_p] * 8 + [c_int32, c_int32] + [c_void_p] * 2, ctypes.c_int),
     "mm_moments1d_reduce": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 4, ctypes.c_int),

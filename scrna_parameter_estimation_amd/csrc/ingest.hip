@@ -250,92 +250,96 @@ __global__ __launch_bounds__(1024) void k_sell_scatter(const int64_t *__restrict
 // range of MM_RANGE_GENES consecutive gene ids): in a sorted row its entries are ONE contiguous segment, and its per-gene state
 // is 48 B x 1024 of LDS -- small enough to assemble every gene's 16-byte groups there instead of storing entry by entry.
 //
-// Step 0: per row, where each gene range starts (R + 1 absolute positions in indices / data), and the structural checks
-// (column indices inside [0, G), strictly ascending).  One wave per row, coalesced index reads; a lane whose range id differs
-// from its predecessor's owns the boundaries in between (no ballots, no search).  The table is stored [range][row], so that the
-// workgroup of (block, range) later reads its bounds as contiguous runs.
-__global__ __launch_bounds__(256) void k_sell_split(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                    const int32_t *__restrict__ cell_order, int64_t n_sel, int32_t n_genes,
-                                                    int32_t n_ranges, int64_t *__restrict__ rowsplit, int32_t *__restrict__ status) {
-  // a workgroup takes 64 consecutive rows (16 per wave) and writes their table transposed: rowsplit[k][row], 512 B runs
+// Steps 0 + 1 in one pass over the column indices: per row, where each gene range starts (R + 1 absolute positions in indices /
+// data) with the structural checks (column indices inside [0, G), strictly ascending), and nnz per (block, gene).
+// A workgroup takes SC_ROWS consecutive rows of ONE block, 64 at a time (4 per wave): a lane whose range id differs from its
+// predecessor's owns the boundaries in between (no ballots, no search); the 64 rows' table leaves through LDS transposed --
+// rowsplit[range][row], so that the scatter's (block, range) workgroup reads its bounds as contiguous runs.  The counts are LDS
+// atomics on 16-bit halves (a block has at most 8192 cells: no carry) merged into blk_cnt by global atomics at the end (integer
+// sums: the result does not depend on the order).
+#ifndef SC_ROWS
+#define SC_ROWS 1024
+#endif
+#define SC_THREADS 1024
+#ifndef SC_AHEAD
+#define SC_AHEAD 4
+#endif
+__global__ __launch_bounds__(SC_THREADS) void k_sell_split_count(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                                 const int32_t *__restrict__ cell_order, const int32_t *__restrict__ blk_cell0,
+                                                                 int32_t n_blocks, int64_t n_sel, int32_t n_genes, int32_t n_ranges,
+                                                                 int64_t *__restrict__ rowsplit, uint32_t *__restrict__ blk_cnt_words,
+                                                                 int32_t *__restrict__ status) {
+  extern __shared__ uint32_t cnt[];                          // [(n_genes + 1) / 2] two 16-bit counters per word
   __shared__ volatile int32_t pos[MM_MAX_RANGES + 1][64];    // offsets inside the row
   __shared__ int64_t rstart[64];
-  int lane = mm_lane(), wv = threadIdx.x >> 6;
-  int64_t rbase = (int64_t)blockIdx.x * 64;
-  int bad = 0;
-  for (int u = 0; u < 16; u++) {
-    int rl = u * 4 + wv;
-    int64_t r = rbase + rl;
-    if (r >= n_sel) break;
-    int cell = cell_order[r];
-    int64_t s = indptr[cell], e = indptr[cell + 1];
-    if (lane == 0) rstart[rl] = s;
-    int prev_g = -1, prev_key = -1;
-    for (int64_t i0 = s; i0 <= e; i0 += 64) {       // position e takes part as the sentinel (range id R)
-      int64_t i = i0 + lane;
-      int g = i < e ? indices[i] : 0x7fffffff;
-      int key = n_ranges;
-      if (i < e) {
-        if (g < 0 || g >= n_genes) {
-          bad = 1;
-          g = g < 0 ? 0 : n_genes - 1;
-        }
-        key = g >> MM_RANGE_SHIFT;
-      }
-      int gp = __shfl_up(g, 1, 64), kp = __shfl_up(key, 1, 64);
-      if (lane == 0) {
-        gp = prev_g;
-        kp = prev_key;
-      }
-      if (i < e && g <= gp) bad = 1;                // not strictly ascending
-      if (i <= e)
-        for (int k = kp + 1; k <= key; k++) pos[k][rl] = (int32_t)(i - s);   // (an unsorted row may leave holes: flagged, not used)
-      prev_g = __shfl(g, 63, 64);
-      prev_key = __shfl(key, 63, 64);
-    }
-  }
-  __syncthreads();
-  int64_t r = rbase + lane;
-  if (r < n_sel)
-    for (int k = wv; k <= n_ranges; k += 4) rowsplit[(int64_t)k * n_sel + r] = rstart[lane] + pos[k][lane];
-  if (bad) atomicOr(status, 2);
-}
-
-// Step 1: nnz per (block, gene).  One workgroup per (block, gene range); LDS counters of the range's genes only.
-__global__ __launch_bounds__(1024) void k_sell_count_ranges(const int32_t *__restrict__ indices, const int32_t *__restrict__ blk_cell0,
-                                                            int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int64_t n_sel,
-                                                            const int64_t *__restrict__ rowsplit, uint16_t *__restrict__ blk_cnt) {
-  __shared__ uint32_t cur[MM_RANGE_GENES];               // counts of this range's genes
-  // workgroup -> (block, range): the R workgroups of one block get ids that are equal mod 8, i.e. land on one XCD (speed only)
-  int x = blockIdx.x & 7, t = blockIdx.x >> 3;
-  int b = (t / n_ranges) * 8 + x, rg = t % n_ranges;
-  if (b >= n_blocks) return;
-  int g0 = rg << MM_RANGE_SHIFT, ngr = min(MM_RANGE_GENES, n_genes - g0);
-  for (int i = threadIdx.x; i < ngr; i += blockDim.x) cur[i] = 0;
-  __syncthreads();
+  constexpr int CH = MM_BLOCK_CELLS / SC_ROWS, NW = SC_THREADS / 64;
+  int b = blockIdx.x / CH, ch = blockIdx.x % CH;
   int c0 = blk_cell0[b], c1 = blk_cell0[b + 1];
-  const int64_t *rsA = rowsplit + (int64_t)rg * n_sel, *rsZ = rsA + n_sel;
-  // a quarter wave per row segment; the NEXT row's segment bounds are fetched while the current one is processed
-  int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
-  int r = c0 + grp;
-  int64_t a = 0, z = 0;
-  if (r < c1) {
-    a = rsA[r];
-    z = rsZ[r];
-  }
-  for (; r < c1; r += ngrp) {
-    int rn = r + ngrp;
-    int64_t an = 0, zn = 0;
-    if (rn < c1) {
-      an = rsA[rn];
-      zn = rsZ[rn];
-    }
-    for (int64_t i = a + sub; i < z; i += 16) atomicAdd(&cur[indices[i] - g0], 1u);
-    a = an;
-    z = zn;
-  }
+  int ra = c0 + ch * SC_ROWS, rz = min(c1, ra + SC_ROWS);
+  if (ra >= rz) return;
+  int lane = mm_lane(), wv = threadIdx.x >> 6;
+  const int nw = (n_genes + 1) / 2;
+  for (int i = threadIdx.x; i < nw; i += SC_THREADS) cnt[i] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < ngr; i += blockDim.x) blk_cnt[(int64_t)b * n_genes + g0 + i] = (uint16_t)cur[i];
+  int bad = 0;
+  for (int rb = ra; rb < rz; rb += 64) {
+    for (int u = 0; u < 64 / NW; u++) {
+      int rl = u * NW + wv;
+      int r = rb + rl;
+      if (r >= rz) break;
+      int cell = cell_order[r];
+      int64_t s = indptr[cell], e = indptr[cell + 1];
+      if (lane == 0) rstart[rl] = s;
+      int prev_g = -1, prev_key = -1;
+      for (int64_t i0 = s; i0 <= e; i0 += 64 * SC_AHEAD) {       // position e takes part as the sentinel (range id R)
+        int gq[SC_AHEAD];
+#pragma unroll
+        for (int q = 0; q < SC_AHEAD; q++) {                       // SC_AHEAD chunks of 64 column indices in flight
+          int64_t i = i0 + 64 * q + lane;
+          gq[q] = i < e ? indices[i] : 0x7fffffff;
+        }
+#pragma unroll
+        for (int q = 0; q < SC_AHEAD; q++) {
+          int64_t i = i0 + 64 * q + lane;
+          if (i0 + 64 * q <= e) {                                  // wave-uniform
+            int g = gq[q];
+            int key = n_ranges;
+            if (i < e) {
+              if (g < 0 || g >= n_genes) {
+                bad = 1;
+                g = g < 0 ? 0 : n_genes - 1;
+              }
+              key = g >> MM_RANGE_SHIFT;
+              atomicAdd(&cnt[g >> 1], 1u << (16 * (g & 1)));
+            }
+            // the predecessor's column and range id: wave_shr:1 in the DPP network, lane 0 takes the previous chunk's last
+            int gp = __builtin_amdgcn_update_dpp(prev_g, g, 0x138, 0xf, 0xf, false);
+            int kp = __builtin_amdgcn_update_dpp(prev_key, key, 0x138, 0xf, 0xf, false);
+            if (i < e && g <= gp) bad = 1;          // not strictly ascending
+            if (i <= e)
+              for (int k = kp + 1; k <= key; k++) pos[k][rl] = (int32_t)(i - s);   // (an unsorted row may leave holes: flagged, not used)
+            prev_g = __builtin_amdgcn_readlane(g, 63);
+            prev_key = __builtin_amdgcn_readlane(key, 63);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    int r = rb + lane;
+    if (r < rz)
+      for (int k = wv; k <= n_ranges; k += NW) rowsplit[(int64_t)k * n_sel + r] = rstart[lane] + pos[k][lane];
+    __syncthreads();
+  }
+  // merge: element (b, g) of the uint16 table [n_blocks][n_genes] is half (e & 1) of word e >> 1, e = b * G + g
+  int64_t e0 = (int64_t)b * n_genes;
+  for (int i = threadIdx.x; i < nw; i += SC_THREADS) {
+    uint32_t w = cnt[i];
+    uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+    int64_t ea = e0 + 2 * i;
+    if (lo) atomicAdd(&blk_cnt_words[ea >> 1], lo << (16 * (ea & 1)));
+    if (hi) atomicAdd(&blk_cnt_words[(ea + 1) >> 1], hi << (16 * ((ea + 1) & 1)));
+  }
+  if (bad) atomicOr(status, 2);
 }
 
 // Step 3, deterministic and write-combined.  Measured on this chip (profiles/README.md, round 2): a 4-byte store to a line that
@@ -757,32 +761,19 @@ int mm_sell_scatter(const int64_t *d_indptr, const int32_t *d_indices, const flo
   return MM_OK;
 }
 
-int mm_sell_split(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, int64_t n_sel, int32_t n_genes,
-                  int32_t n_ranges, int64_t *d_rowsplit, int32_t *d_status, void *stream) {
-  MM_ARG(d_indptr && d_indices && d_cell_order && d_rowsplit && d_status && n_sel >= 0 && n_genes > 0);
+int mm_sell_split_count(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
+                        int32_t n_blocks, int64_t n_sel, int32_t n_genes, int32_t n_ranges, int64_t *d_rowsplit, uint16_t *d_blk_cnt,
+                        int32_t *d_status, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_cell_order && d_blk_cell0 && d_rowsplit && d_blk_cnt && d_status);
+  MM_ARG(n_blocks >= 0 && n_sel >= 0 && n_genes > 0 && ((uintptr_t)d_blk_cnt & 3) == 0);
   MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
-  if (n_sel == 0) return MM_OK;
-  int64_t blocks = (n_sel + 63) / 64;
-  MM_ARG(blocks < 2147483647LL);
-  hipLaunchKernelGGL(k_sell_split, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_cell_order, n_sel,
-                     n_genes, n_ranges, d_rowsplit, d_status);
-  MM_LAUNCH_CHECK();
-  return MM_OK;
-}
-
-int mm_sell_count_ranges(const int64_t *d_indptr, const int32_t *d_indices, const int32_t *d_cell_order, const int32_t *d_blk_cell0,
-                         int32_t n_blocks, int32_t n_genes, int32_t n_ranges, int64_t n_sel, const int64_t *d_rowsplit,
-                         uint16_t *d_blk_cnt, void *stream) {
-  (void)d_indptr;
-  (void)d_cell_order;   // the row positions come from d_rowsplit; kept in the signature next to mm_sell_count's
-  MM_ARG(d_indices && d_blk_cell0 && d_rowsplit && d_blk_cnt);
-  MM_ARG(n_blocks >= 0 && n_genes > 0 && n_sel >= 0);
-  MM_ARG(n_ranges == (n_genes + MM_RANGE_GENES - 1) / MM_RANGE_GENES && n_ranges <= MM_MAX_RANGES);
-  if (n_blocks == 0) return MM_OK;
-  int64_t grid = (int64_t)((n_blocks + 7) / 8) * n_ranges * 8;
+  if (n_blocks == 0 || n_sel == 0) return MM_OK;
+  int64_t grid = (int64_t)n_blocks * (MM_BLOCK_CELLS / SC_ROWS);
   MM_ARG(grid < 2147483647LL);
-  hipLaunchKernelGGL(k_sell_count_ranges, dim3((unsigned)grid), dim3(1024), 0, (hipStream_t)stream, d_indices, d_blk_cell0, n_blocks,
-                     n_genes, n_ranges, n_sel, d_rowsplit, d_blk_cnt);
+  size_t shm = (size_t)((n_genes + 1) / 2) * 4;
+  MM_HIP(hipFuncSetAttribute((const void *)k_sell_split_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_sell_split_count, dim3((unsigned)grid), dim3(SC_THREADS), shm, (hipStream_t)stream, d_indptr, d_indices,
+                     d_cell_order, d_blk_cell0, n_blocks, n_sel, n_genes, n_ranges, d_rowsplit, (uint32_t *)d_blk_cnt, d_status);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

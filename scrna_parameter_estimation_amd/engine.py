@@ -204,7 +204,8 @@ class CountBlocks:
         self.d_blk_cell0 = dev(self.blk_cell0)
         self.d_blk_group = dev(self.blk_group)
         self.d_grp_blk0 = dev(self.grp_blk0)
-        blk_cnt = zeros((nb, G), torch.int16)
+        blk_cnt_buf = zeros((nb * G + 2,), torch.int16)     # (the fused split + count merges 16-bit halves by 32-bit atomics)
+        blk_cnt = blk_cnt_buf[:nb * G].view(nb, G)
         status = zeros((1,), torch.int32)
         bad_data = ValueError(f"count matrix must hold positive integer counts <= {MAX_COUNT} with valid column indices")
         # Range-partitioned ingest (rows with ascending column indices: every canonical CSR): a workgroup owns (block, range of
@@ -215,12 +216,10 @@ class CountBlocks:
         if R > MAX_RANGES:
             raise ValueError(f"at most {MAX_RANGES * RANGE_GENES} genes per ingest")
         rowsplit = empty((R + 1, max(1, n_sel)), torch.int64)     # [range][row]
-        call("mm_sell_split", P(csr.indptr), P(csr.indices), P(self.d_cell_order), n_sel, G, R, P(rowsplit), P(status), s)
+        call("mm_sell_split_count", P(csr.indptr), P(csr.indices), P(self.d_cell_order), P(self.d_blk_cell0), nb, n_sel, G, R,
+             P(rowsplit), P(blk_cnt_buf), P(status), s)
         self.ranged = (int(status.item()) & 2) == 0
-        if self.ranged:
-            call("mm_sell_count_ranges", P(csr.indptr), P(csr.indices), P(self.d_cell_order), P(self.d_blk_cell0), nb, G, R,
-                 n_sel, P(rowsplit), P(blk_cnt), s)
-        else:       # unsorted rows (or column indices out of range: reported by the count kernel): the unpartitioned kernels
+        if not self.ranged:       # unsorted rows (or column indices out of range: reported by the count kernel): the unpartitioned kernels
             status.zero_()
             call("mm_sell_count", P(csr.indptr), P(csr.indices), P(csr.data), P(self.d_cell_order), P(self.d_blk_cell0), nb, G,
                  P(blk_cnt), P(status), s)

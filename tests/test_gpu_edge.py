@@ -180,7 +180,7 @@ def test_mean_filter_tie_follows_scipy_rounding(eng):
 
 def test_unsorted_rows_take_the_unpartitioned_ingest(eng):
     """The range-partitioned ingest needs ascending column indices inside a row; a device CSR whose rows are not sorted is
-    detected (mm_sell_split) and goes through the unpartitioned kernels -- same count blocks, same moments."""
+    detected (mm_sell_split_count) and goes through the unpartitioned kernels -- same count blocks, same moments."""
     import torch
 
     X, gid, ng = _edge_matrix()
