@@ -305,18 +305,26 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
                      const double *d_slot_nobs, const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4],
                      int32_t num_boot, int64_t ld, double *d_out_corr, void *stream);
 
-/* ---- synthetic data generator (replaces memento/simulate.py:52-68 independent-gene branch and :91-115) ----
+/* ---- synthetic data generator (replaces memento/simulate.py:52-89 and :91-115) ----
  * Counter-based: transcriptome count z[cell][gene] ~ NB(mean[gene], size theta[gene]) is a pure function of (seed_z, cell, gene),
  * so nothing dense is ever stored.  One launch per pass, selected by `mode`:
  *   0: d_totals[cell]  = sum_g z                         (needed by the hypergeometric capture)
  *   1: d_row_nnz[cell] = number of genes with a captured count > 0
  *   2: write row `cell` of the captured CSR at d_row_ptr[cell] (d_out_indices int32 ascending, d_out_data float32 counts)
+ *   3: d_raw_totals[cell] = sum_g nb (Gaussian-copula branch only, before the rescaling below)
  * process 0: multivariate hypergeometric capture of rint(q[cell] * total) molecules (simulate.py:104-109; needs d_totals);
  *         1: Poisson capture x ~ Poisson(q[cell] * z) (simulate.py:110-112);  2: no capture (x = z, d_qs may be NULL).
+ * Gaussian-copula branch (simulate.py:70-89): d_gauss != NULL holds the correlated standard-normal scores, [gene][cell] float32
+ * (Cholesky factor of the correlation matrix x white noise from mm_std_normal: a library GEMM on the caller's side); then
+ * nb = nbinom.ppf(Phi(score)) replaces the own NB draw, and with d_cell_size != NULL (needs d_raw_totals from a mode-3 pass)
+ * z = rint(nb / raw_total[cell] * cell_size[cell]) (simulate.py:86-89).  d_gauss == NULL: independent branch (:66-68).
  * Draws are NOT numpy's (different generators): statistical equivalence only. */
 int mm_simulate(const double *d_mean, const double *d_theta, int32_t n_genes, int64_t n_cells, const double *d_qs, uint64_t seed_z,
                 uint64_t seed_capture, int32_t process, int32_t mode, int64_t *d_totals, int64_t *d_row_nnz, const int64_t *d_row_ptr,
-                int32_t *d_out_indices, float *d_out_data, void *stream);
+                int32_t *d_out_indices, float *d_out_data, const float *d_gauss, const double *d_cell_size, int64_t *d_raw_totals,
+                void *stream);
+/* n independent standard normals (float32), element i a pure function of (seed, i). */
+int mm_std_normal(uint64_t seed, int64_t n, float *d_out, void *stream);
 
 #ifdef __cplusplus
 }

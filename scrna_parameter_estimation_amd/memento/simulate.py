@@ -2,15 +2,18 @@
 (SURVEY.md section 8f rank 4), same function names and argument meaning:
 
   extract_parameters(data, q, min_mean)                       reference simulate.py:13-33
-  simulate_transcriptomes(n_cells, means, variances, Nc, norm_cov='indep')      :52-68  (independent negative binomials)
+  simulate_transcriptomes(n_cells, means, variances, Nc, norm_cov)              :52-89  norm_cov='indep': independent negative
+                                                                                        binomials; None / matrix: Gaussian copula
   capture_sampling(transcriptomes, q, q_sq=None, process='hyper')               :91-115 (hypergeometric or Poisson capture)
 
 Differences, all forced by scale: the reference returns dense cells x genes numpy arrays (80 GB at 1M x 20k); here a
 ``Transcriptomes`` object only carries the negative-binomial parameters and a seed -- every count is a pure function of
 (seed, cell, gene) and is regenerated inside the HIP kernel (csrc/simulate.hip) -- and ``capture_sampling`` returns the captured
 counts as an ``engine.DeviceCSR`` resident in HBM (``.to_scipy()`` for small cases), ready for ``setup_memento(device_csr=...)``.
-The Gaussian-copula branch of simulate_transcriptomes (``norm_cov`` None or a matrix, simulate.py:70-89: a dense
-genes x genes covariance and scipy's nbinom.ppf) is not built.  Random draws are not numpy's: parity is statistical
+The Gaussian-copula branch (``norm_cov`` None or a genes x genes matrix, simulate.py:70-89) keeps ONE dense array, the correlated
+standard-normal scores [gene][cell] in fp32 (Cholesky factor of the correlation matrix, computed on the host, times white noise
+from mm_std_normal -- a library GEMM); the kernel turns a score into nbinom.ppf(Phi(score)) and rescales the cell to its size on
+the fly.  Random draws are not numpy's: parity is statistical
 (tests/test_gpu_simulate.py recovers the simulated moments through the HIP estimators, as the reference's
 analysis/simulation/estimator_validation.ipynb does).  ``sequencing_sampling`` is dead code in the reference (:118-128).
 """
@@ -25,18 +28,29 @@ from .. import _lib, engine
 class Transcriptomes:
     """Lazy cells x genes matrix of NB(mean_g, theta_g) molecule counts (reference: the array simulate_transcriptomes returns)."""
 
-    def __init__(self, n_cells, means, thetas, seed):
+    def __init__(self, n_cells, means, thetas, seed, scores=None, cell_sizes=None):
+        """``scores``: device float32 [genes][cells] of correlated standard-normal scores (copula branch; None = independent
+        genes); ``cell_sizes``: per-cell molecule totals the copula branch rescales to (None = the raw quantiles)."""
         self.shape = (int(n_cells), int(len(means)))
         self.means = np.asarray(means, dtype=np.float64)
         self.thetas = np.asarray(thetas, dtype=np.float64)
         self.seed = int(seed) & ((1 << 64) - 1)
         self._d_mu, self._d_theta = engine.dev(self.means), engine.dev(self.thetas)
         self._totals = None
+        self._scores = scores
+        self._d_cell_size = None if cell_sizes is None else engine.dev(np.asarray(cell_sizes, dtype=np.float64))
+        self._raw_totals = None
+        if scores is not None:
+            torch = engine._torch()
+            assert tuple(scores.shape) == (self.shape[1], self.shape[0]) and scores.dtype == torch.float32 and scores.is_contiguous()
+            self._raw_totals = engine.empty((max(1, self.shape[0]),), torch.int64)
+            self._launch(None, 0, 2, 3)
 
     def _launch(self, d_qs, seed_c, process, mode, totals=None, row_nnz=None, row_ptr=None, idx=None, val=None):
         P = engine.P
         _lib.call("mm_simulate", P(self._d_mu), P(self._d_theta), self.shape[1], self.shape[0], P(d_qs), self.seed,
-                  int(seed_c) & ((1 << 64) - 1), int(process), int(mode), P(totals), P(row_nnz), P(row_ptr), P(idx), P(val), engine._stream())
+                  int(seed_c) & ((1 << 64) - 1), int(process), int(mode), P(totals), P(row_nnz), P(row_ptr), P(idx), P(val),
+                  P(self._scores), P(self._d_cell_size), P(self._raw_totals), engine._stream())
 
     def totals(self):
         """Molecules per cell (device int64 tensor), computed once."""
@@ -105,18 +119,45 @@ def extract_parameters(data, q=0.1, min_mean=0.001):
     return (x_mean[good_idx], x_var[good_idx]), (z_mean[good_idx], z_var[good_idx]), Nc, good_idx
 
 
-def simulate_transcriptomes(n_cells, means, variances, Nc=None, norm_cov='indep', seed=0):
-    """Independent negative-binomial transcriptomes (reference simulate.py:52-68): dispersion = (var - mean) / mean^2, floored at
-    1e-5, theta = 1 / dispersion.  ``Nc`` is unused by this branch in the reference as well.  Returns a lazy ``Transcriptomes``."""
-    if not isinstance(norm_cov, str):
-        raise NotImplementedError("HIP path: only the independent-gene branch (norm_cov='indep', simulate.py:66-68); the "
-                                  "Gaussian-copula branch needs a dense genes x genes covariance")
+def make_spd_matrix(n_dim, rng=None):
+    """A random symmetric positive-definite matrix (what sklearn.datasets.make_spd_matrix builds: U (1 + diag(rand)) V^T from the
+    SVD of A^T A, A uniform): the reference's default covariance of the copula (simulate.py:72)."""
+    rng = np.random if rng is None else rng
+    A = rng.random((n_dim, n_dim))
+    U, _, Vt = np.linalg.svd(A.T @ A, full_matrices=False)
+    return U @ (1.0 + np.diag(rng.random(n_dim))) @ Vt
+
+
+def correlated_scores(n_cells, corr, seed):
+    """Device float32 [genes][cells]: standard-normal scores with correlation matrix ``corr`` = chol(corr) x white noise."""
+    torch = engine._torch()
+    G = corr.shape[0]
+    L = np.linalg.cholesky(np.asarray(corr, dtype=np.float64))
+    noise = engine.empty((G, max(1, n_cells)), torch.float32)
+    _lib.call("mm_std_normal", int(seed) & ((1 << 64) - 1), G * max(1, n_cells), engine.P(noise), engine._stream())
+    return torch.matmul(engine.dev(L.astype(np.float32)), noise)[:, :n_cells].contiguous()      # plain library GEMM
+
+
+def simulate_transcriptomes(n_cells, means, variances, Nc=None, norm_cov=None, seed=0):
+    """reference simulate.py:52-89.  dispersion = (var - mean) / mean^2, floored at 1e-5, theta = 1 / dispersion.
+    ``norm_cov`` a string (the reference passes 'indep'): independent negative binomials, ``Nc`` unused (as in the reference).
+    ``norm_cov`` None or a genes x genes covariance: Gaussian copula -- scores ~ N(0, corr(norm_cov)), count = nbinom.ppf(Phi(score)),
+    every cell rescaled to a size drawn from ``Nc`` with np.random.choice (the global numpy stream, as the reference does) and
+    rounded.  Returns a lazy ``Transcriptomes``."""
     means = np.asarray(means, dtype=np.float64)
     variances = np.asarray(variances, dtype=np.float64)
     with np.errstate(divide="ignore", invalid="ignore"):
         dispersions = (variances - means) / means ** 2
     dispersions[~(dispersions > 0)] = 1e-5                                              # simulate.py:63 (< 0; also 0 and 0/0)
-    return Transcriptomes(n_cells, means, 1.0 / dispersions, seed)
+    thetas = 1.0 / dispersions
+    if isinstance(norm_cov, str):
+        return Transcriptomes(n_cells, means, thetas, seed)
+    n_genes = len(means)
+    cov = make_spd_matrix(n_genes) if norm_cov is None else np.asarray(norm_cov, dtype=np.float64)
+    sd = np.sqrt(np.diag(cov))
+    scores = correlated_scores(n_cells, cov / np.outer(sd, sd), seed + 0x5C0FE)         # (the copula's mean vector cancels: :80)
+    cell_sizes = np.random.choice(np.asarray(Nc), size=n_cells)                         # simulate.py:83
+    return Transcriptomes(n_cells, means, thetas, seed, scores=scores, cell_sizes=cell_sizes)
 
 
 def capture_sampling(transcriptomes, q, q_sq=None, process='hyper', seed=42343):

@@ -111,3 +111,77 @@ def test_simulated_moments_are_recovered_through_the_hip_estimators():
     memento.create_groups(adata, label_columns=["grp"])
     memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
     assert len(adata.uns["memento"]["gene_list"]) > 0.5 * G
+
+
+def test_copula_quantiles_equal_scipy_on_the_same_scores():
+    """Gaussian-copula branch, kernel level: nb = nbinom.ppf(Phi(score)) (reference simulate.py:80-81).  The scores live on the
+    device, so scipy can be asked for the quantiles of exactly the same uniforms: the counts must agree element by element (a
+    uniform within rounding of a CDF step may fall on either side: at most a handful of +-1 differences in 240,000 draws)."""
+    import scipy.stats as stats
+
+    from scrna_parameter_estimation_amd import engine
+    from scrna_parameter_estimation_amd.memento import simulate
+
+    n = 30_000
+    means = np.array([0.05, 0.4, 2.0, 9.0, 25.0, 140.0, 2500.0, 0.0])
+    variances = np.array([0.06, 0.9, 3.0, 40.0, 400.0, 900.0, 2600.0, 0.0])     # (2500, 2600): nearly Poisson, theta = 62,500
+    rng = np.random.default_rng(4)
+    A = rng.normal(size=(8, 8))
+    cov = A @ A.T + 0.5 * np.eye(8)
+    sd = np.sqrt(np.diag(cov))
+    scores = simulate.correlated_scores(n, cov / np.outer(sd, sd), seed=9)
+    Y = engine.host(scores).astype(np.float64)                                  # [genes][cells]
+    assert Y.shape == (8, n) and abs(Y.mean()) < 0.02 and abs(Y.std() - 1) < 0.02
+    np.testing.assert_allclose(np.corrcoef(Y), cov / np.outer(sd, sd), atol=0.03)
+    disp = (variances - means) / np.where(means > 0, means, 1) ** 2
+    disp[~(disp > 0)] = 1e-5
+    t = simulate.Transcriptomes(n, means, 1.0 / disp, seed=1, scores=scores)    # no cell sizes: the raw quantiles
+    Z = _dense(t.to_device_csr())
+    want = np.zeros_like(Z)
+    for g in range(7):
+        want[:, g] = stats.nbinom.ppf(stats.norm.cdf(Y[g]), *simulate.convert_params_nb(means[g], 1.0 / disp[g]))
+    diff = np.abs(Z - want)
+    assert diff.max() <= 1 and (diff != 0).sum() <= 5, ((diff != 0).sum(), diff.max())
+    assert (Z[:, 7] == 0).all()
+
+
+def test_copula_transcriptomes_cell_sizes_and_dependence():
+    """Gaussian-copula branch through the API (simulate.py:70-89): every cell sums to its drawn size up to the rounding of its
+    genes, correlated gene pairs come out rank-correlated as a Gaussian copula predicts (Spearman = 6/pi asin(rho/2)),
+    uncorrelated ones do not, and the capture step runs on top."""
+    import scipy.stats as stats
+
+    from scrna_parameter_estimation_amd.memento import simulate
+
+    rng = np.random.default_rng(7)
+    n, G = 30_000, 40
+    means = rng.uniform(8, 60, size=G)
+    variances = means + 0.2 * means ** 2
+    cov = np.eye(G)
+    cov[0, 1] = cov[1, 0] = 0.8
+    cov[2, 3] = cov[3, 2] = -0.6
+    cov *= np.outer(np.linspace(1, 3, G), np.linspace(1, 3, G))                 # a covariance, not a correlation matrix
+    Nc = rng.integers(1200, 1500, size=500)
+    np.random.seed(3)
+    t = simulate.simulate_transcriptomes(n, means, variances, Nc, norm_cov=cov, seed=5)
+    Z = _dense(t.to_device_csr())
+    np.random.seed(3)
+    sizes = np.random.choice(Nc, size=n)                                        # the draw the call made (global numpy stream)
+    assert np.abs(Z.sum(axis=1) - sizes).max() <= G / 2 + 1 and abs((Z.sum(axis=1) - sizes).mean()) < 0.5
+    sp01 = stats.spearmanr(Z[:, 0], Z[:, 1])[0]
+    sp23 = stats.spearmanr(Z[:, 2], Z[:, 3])[0]
+    sp45 = stats.spearmanr(Z[:, 4], Z[:, 5])[0]
+    assert abs(sp01 - 6 / np.pi * np.arcsin(0.4)) < 0.05, sp01
+    assert abs(sp23 + 6 / np.pi * np.arcsin(0.3)) < 0.05, sp23
+    assert abs(sp45) < 0.03, sp45
+    rel = Z.mean(axis=0) / Z.mean(axis=0).sum() / (means / means.sum()) - 1     # relative abundances follow the NB means
+    assert np.abs(rel).max() < 0.03
+    qs, cap = simulate.capture_sampling(t, 0.1, process='hyper')
+    X = _dense(cap)
+    assert (X <= Z).all()
+    np.testing.assert_array_equal(X.sum(axis=1), np.rint(0.1 * Z.sum(axis=1)))
+    # default covariance (norm_cov=None): a random SPD matrix, as the reference draws with sklearn's make_spd_matrix
+    S = simulate.make_spd_matrix(12, np.random.default_rng(0))
+    assert np.allclose(S, S.T) and np.linalg.eigvalsh(S).min() > 0
+    t2 = simulate.simulate_transcriptomes(2000, means[:12], variances[:12], Nc, seed=6)
+    assert _dense(t2.to_device_csr()).shape == (2000, 12)
