@@ -25,6 +25,7 @@ ORDER_BIG_CAP_2D = 4096
 PACK_C0 = 220.0
 PACK_C1 = 3.0
 PACK_WAVES = 2000
+PACK_WAVES3 = 2750       # tile target when a third wave per SIMD pays (pack_lanes)
 # (b) measured time of one bin step of a wave of L chains running as the OLDER wave of its SIMD, us (tools/replay_balance.py,
 # C3, round-2 kernel with the guarded fp32 search loops): used to rank tiles by length for the dispatch order (pair_tiles)
 _PACK_L = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 56, 64)
@@ -338,14 +339,17 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
     def lanes_for(budget):
         return np.clip(np.floor((budget / Ks - C0) / C1), 1, 64)
 
-    lo_b, hi_b = C0 + C1, float(Ks.max()) * (C0 + 64 * C1) * 4.0
-    for _ in range(50):
-        mid = 0.5 * (lo_b + hi_b)
-        if (1.0 / lanes_for(mid)).sum() > target_waves:
-            lo_b = mid
-        else:
-            hi_b = mid
-    lanes = np.maximum.accumulate(lanes_for(hi_b).astype(np.int64))
+    def resident(n_waves):
+        lo_b, hi_b = C0 + C1, float(Ks.max()) * (C0 + 64 * C1) * 4.0
+        for _ in range(50):
+            mid = 0.5 * (lo_b + hi_b)
+            if (1.0 / lanes_for(mid)).sum() > n_waves:
+                lo_b = mid
+            else:
+                hi_b = mid
+        return np.maximum.accumulate(lanes_for(hi_b).astype(np.int64))
+
+    lanes = resident(target_waves)
     c = PACK_COST
     # MANY chains (2D pair lists, hundreds of groups): 64-wide tiles no longer fit the resident wave slots, or they fit only
     # because even the longest chains were made 64 wide (a 64-wide step costs 6x a lone chain's, and that tile then runs
@@ -389,6 +393,16 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
                      chosen="work-bound" if use_work_bound else "resident")
     if use_work_bound:
         lanes = lanes_w
+    elif target_waves == PACK_WAVES and PACK_WAVES3 > PACK_WAVES:
+        # A third wave per SIMD (the kernels' 3-wave build, taken above 2048 tiles): narrower tiles for the same chains.  It
+        # pays when the longest tile gets shorter -- the waves of this kernel leave ~40 % of the issue slots empty, a third wave
+        # fills some -- and costs when the longest chain is already alone in its tile (then only the work grows).  Measured
+        # (tools/pack_sweep.py, 2000 vs 2750 tiles): C3 shapes with 250k / 500k / 1M cells 2889 -> 2738, 3162 -> 2993,
+        # 3815 -> 3591 ms (model: longest tile -8 to -10 %); C2 368 -> 391 ms (model: longest tile unchanged).
+        lanes3 = resident(PACK_WAVES3)
+        if float((1.0 / lanes3).sum()) <= 3 * PAIR_SLOTS and float((Ks * c[lanes3 - 1]).max()) <= 0.95 * longest_resident:
+            lanes = lanes3
+            PACK_LAST.update(chosen="resident, 3 waves / SIMD", tiles_resident=float((1.0 / lanes3).sum()))
     return _tiles_from_lanes(lanes, n_act)
 
 

@@ -1,6 +1,6 @@
 """Sweep of the replay kernel's lane-packing constants (engine.PACK_C0 / PACK_C1 / PACK_WAVES) on one shape, in ONE process.
 These are module attributes the tools set directly; the product path reads no environment variable.
-usage: python tools/pack_sweep.py [config=C3] "c0,c1,waves[,max_resident[,pair_slots]]" ..."""
+usage: python tools/pack_sweep.py [config=C3 | C3@cells[@num_boot]] "c0,c1,waves[,max_resident[,pair_slots]]" ..."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch, scipy.sparse as sp
@@ -9,7 +9,11 @@ from scrna_parameter_estimation_amd import AnnDataLite, engine, memento, _lib
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 combos = [tuple(float(x) for x in a.split(",")) for a in sys.argv[2:]] or [(220, 3, 2000)]
-cfg = bench.CONFIGS[name]
+cfg = dict(bench.CONFIGS[name.split("@")[0]])
+if "@" in name:                       # e.g. C3@500000 or C3@500000@1000: the same shape with other cells / bootstraps
+    cfg["cells"] = int(name.split("@")[1])
+    if len(name.split("@")) > 2:
+        cfg["num_boot"] = int(name.split("@")[2])
 N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
 ng = cfg["n_cond"] * cfg["n_rep"]
 csr = bench.synth_device_csr(cfg, 20250117, torch)
@@ -35,4 +39,4 @@ for combo in combos:
     bs.run(skip, r[0], r[1], m["mv_regressor"]["all"], fill_mode=1)
     _lib.call("mm_timer_end", timer, s)
     _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(ms))
-    print(f"{name} C0={c0:g} C1={c1:g} waves={int(waves)} -> tiles {bs.n_tiles} ({engine.PACK_LAST.get('chosen')})  bootstrap {ms.value:.0f} ms", flush=True)
+    print(f"{name} C0={c0:g} C1={c1:g} waves={int(waves)} -> tiles {bs.n_tiles} ({engine.PACK_LAST.get('chosen')})  bootstrap {ms.value:.0f} ms; model: longest tile {engine.PACK_LAST.get('longest_resident', 0) * B * 1e-6:.2f} s, work / rate {engine.PACK_LAST.get('work_resident', 0) * B * 1e-6:.2f} s, chains {engine.PACK_LAST.get('chains')}, K max {int(bs.K.max())} mean {bs.K[bs.K >= 2].mean():.0f}", flush=True)
