@@ -623,6 +623,7 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
 
     G_all = len(st.gene_idx)
     st.refill_stats = dict(chains=0, chains_refilled=0, genes=0, genes_refilled=0, gene_refilled=np.zeros(G_all, dtype=bool))
+    st.last_bootstrap = None                   # the previous call's replicate rows (GBs) go back to the caching allocator BEFORE this call allocates its own
     if max_rows is None:                       # replicate buffers sized to the free HBM (288 GB on MI355X)
         max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
     chunk = G_all if strict else max(1, int(max_rows) // max(1, ng))   # strict replay is sequential over all genes
@@ -679,6 +680,7 @@ def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', f
     chunk = max(1, int(max_rows) // max(1, ng))
     cols = {k: [] for k in ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')}
     bs = rows = None
+    st.last_bootstrap = None                   # (see ht_1d_moments: free the previous call's replicate rows first)
     for g0 in range(0, G_all, chunk):
         g1 = min(G_all, g0 + chunk)
         G = g1 - g0
@@ -824,6 +826,7 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         adata = adata.copy()
     m = adata.uns['memento']
     st = m['_hip']
+    st.last_bootstrap2d = None                 # (free the previous call's replicate rows before this call allocates its own)
     groups = m['groups']
     ng = len(groups)
     Nc_list = np.array([m['group_cells'][g].shape[0] for g in groups], dtype=np.float64)
