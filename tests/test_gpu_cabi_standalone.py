@@ -1,5 +1,6 @@
 """The C-ABI stands on its own: a process that imports neither torch nor this package drives
-mm_csr_rowsum -> mm_sell_count / _layout / _scatter -> mm_moments1d_sell -> mm_moments1d_reduce with nothing but ctypes, numpy and
+mm_csr_rowsum -> mm_sell_split_count / _layout / _scatter_ranges (the product's ingest) -> mm_moments1d_sell -> mm_moments1d_reduce with
+nothing but ctypes, numpy and
 the library's own mm_malloc / mm_memcpy_* helpers (include/memento_hip.h:41-47) -- exactly what INTEGRATION.md's reference-side
 stub does -- and gets the oracle's moment sums."""
 
@@ -56,8 +57,10 @@ counts = np.bincount(gid, minlength=ng)
 blk_cell0 = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
 nb, ns = ng, (G + 63) // 64
 d_order, d_bc0 = to_dev(order), to_dev(blk_cell0)
-d_cnt, d_status = zeros_dev(nb * G * 2), zeros_dev(4)
-ck(lib.mm_sell_count(d_ip, d_ix, d_dt, d_order, d_bc0, i32(nb), i32(G), d_cnt, d_status, None))
+n_sel, R = len(order), (G + 1023) // 1024          # ranges of MM_RANGE_GENES = 1024 gene ids
+d_cnt, d_status = zeros_dev(nb * G * 2 + 4), zeros_dev(4)
+d_split = dmalloc((R + 1) * n_sel * 8)
+ck(lib.mm_sell_split_count(d_ip, d_ix, d_order, d_bc0, i32(nb), i64(n_sel), i32(G), i32(R), d_split, d_cnt, d_status, None))
 assert to_host(d_status, (1,), np.int32)[0] == 0
 d_rank, d_perm, d_sw = dmalloc(nb * G * 4), dmalloc(nb * ns * 64 * 4), dmalloc(nb * ns * 4)
 d_sp, d_itp, d_rows, d_items = dmalloc(nb * (ns + 1) * 4), dmalloc(nb * (ns + 1) * 4), dmalloc(nb * 8), dmalloc(nb * 4)
@@ -67,7 +70,9 @@ base = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
 ibase = np.concatenate([[0], np.cumsum(items)]).astype(np.int64)
 d_base, d_ibase = to_dev(base[:-1]), to_dev(ibase[:-1])
 d_ent = zeros_dev(int(base[-1]) * 1024)
-ck(lib.mm_sell_scatter(d_ip, d_ix, d_dt, d_order, d_bc0, i32(nb), i32(G), d_rank, d_sp, d_base, d_ent, None))
+ck(lib.mm_sell_scatter_ranges(d_ip, d_ix, d_dt, d_order, d_bc0, i32(nb), i32(G), i32(R), i64(n_sel), d_split, d_rank, d_sp, d_base, d_ent,
+                              d_status, None))
+assert to_host(d_status, (1,), np.int32)[0] == 0
 d_inv = to_dev(inv_sf[order].astype(np.float64))
 d_slab = dmalloc(int(ibase[-1]) * 64 * 32)
 ck(lib.mm_moments1d_sell(d_ent, d_base, d_sw, d_sp, d_itp, d_ibase, d_bc0, d_inv, i32(nb), i32(G), d_slab, None))
@@ -76,7 +81,7 @@ d_S, d_sx, d_mx = dmalloc(3 * ng * G * 8), dmalloc(ng * G * 8), dmalloc(ng * G *
 ck(lib.mm_moments1d_reduce(d_slab, d_rank, d_itp, d_ibase, d_gb0, i32(ng), i32(G), d_S, d_sx, d_mx, None))
 S, sx, mx = to_host(d_S, (3, ng, G), np.float64), to_host(d_sx, (ng, G), np.uint64), to_host(d_mx, (ng, G), np.uint32)
 np.savez(sys.argv[3], rowsum=rowsum, S=S, sx=sx, mx=mx)
-for p in (d_ip, d_ix, d_dt, d_rs, d_order, d_bc0, d_cnt, d_status, d_rank, d_perm, d_sw, d_sp, d_itp, d_rows, d_items, d_base, d_ibase, d_ent, d_inv,
+for p in (d_ip, d_ix, d_dt, d_rs, d_order, d_bc0, d_cnt, d_status, d_split, d_rank, d_perm, d_sw, d_sp, d_itp, d_rows, d_items, d_base, d_ibase, d_ent, d_inv,
           d_slab, d_gb0, d_S, d_sx, d_mx):
     ck(lib.mm_free(p))
 print(json.dumps({"torch_loaded": "torch" in sys.modules, "version": lib.mm_version()}))
