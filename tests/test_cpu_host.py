@@ -325,6 +325,19 @@ def test_pack_and_pair_tiles_are_a_valid_schedule():
     assert lb[0] < 8 and lb[-1] == 64 or lb[-2] == 64                  # heaviest chain nearly alone, lightest in full waves
     assert cost.max() <= max(Kb[0] * engine.PACK_COST[0], engine.PACK_TAIL * cost.sum() / engine.PACK_RATE) * 1.001
     assert len(np.unique(engine.pair_tiles(sb, nb, Kb))) == len(Kb)
+    # a heavy head of long chains that 2,000 tiles cannot give lanes of their own (BASELINE configs[2]'s shape): narrower tiles in
+    # up to three waves per SIMD shorten the longest tile, and the packer takes them; every chain still has exactly one slot
+    Kc = np.sort(np.concatenate([rng.integers(250, 351, size=600), np.clip(rng.lognormal(np.log(70), 0.45, 43_000), 2, 249).astype(int)]))[::-1]
+    sc, nc = engine.pack_lanes(Kc, engine.PACK_WAVES)
+    assert engine.PACK_LAST["chosen"].startswith("resident, 3 waves") and 2048 < nc <= 3 * engine.PAIR_SLOTS
+    assert len(np.unique(sc)) == len(Kc) and len(np.unique(engine.pair_tiles(sc, nc, Kc))) == len(Kc)
+    lc = np.bincount(sc // 64, minlength=nc)
+    kc = np.zeros(nc)
+    np.maximum.at(kc, sc // 64, Kc)
+    assert (kc * engine.PACK_COST[lc - 1]).max() <= 0.95 * engine.PACK_LAST["longest_resident"]
+    # ... and it keeps 2,000 tiles when the longest chain already sits alone in its tile (the uniform K above)
+    engine.pack_lanes(K, engine.PACK_WAVES)
+    assert engine.PACK_LAST["chosen"] == "resident"
     # degenerate inputs
     assert engine.pack_lanes(np.zeros(0), 2000) [1] == 0
     s1, n1 = engine.pack_lanes(np.array([7]), 2000)
