@@ -466,8 +466,8 @@ class Bootstrap1D:
         # per (group, sf_bin) cell counts (the zero-count bins come from these)
         bins_sorted = np.asarray(sf_bin_cells, dtype=np.uint8)[b.cell_order]
         grp_of_sorted = np.repeat(np.arange(self.ng), b.grp_ncells)
-        self.grp_bin_cells = np.zeros((self.ng, self.n_bins), dtype=np.uint32)
-        np.add.at(self.grp_bin_cells, (grp_of_sorted, bins_sorted), 1)
+        self.grp_bin_cells = np.bincount(grp_of_sorted.astype(np.int64) * self.n_bins + bins_sorted, minlength=self.ng * self.n_bins) \
+            .reshape(self.ng, self.n_bins).astype(np.uint32)
         d_bins = dev(bins_sorted)
         pairbase = np.full(b.G, -1, dtype=np.int32)
         pairbase[self.gene_idx] = (np.arange(self.n_tested) * self.ng).astype(np.int32)

@@ -141,7 +141,7 @@ def asl_from_stats(stats_arr, approx, fetch_rows, num_cpus=1, resampling='bootst
     if len(need):
         rows = fetch_rows(need)
         jobs = [(rows[i], float(c[t]), centred) for i, t in enumerate(need)]
-        if num_cpus and num_cpus > 1 and len(jobs) > 1:
+        if num_cpus and num_cpus > 1 and (len(jobs) > 1 or defer):       # (a lone deferred fit still overlaps the caller's device work)
             with _main_hidden():        # workers are spawned on submit
                 it = get_pool(num_cpus).map(_tail_job, jobs, chunksize=max(1, len(jobs) // (4 * num_cpus)))
         else:

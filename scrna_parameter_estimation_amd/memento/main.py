@@ -242,9 +242,11 @@ def _bin_size_factor(adata):
     st.sf_bin = bin_id.astype(np.uint8) if table.shape[0] <= 256 else None
     st.sf_table = np.nan_to_num(table, nan=1.0)          # empty bins are never referenced
     m['all_approx_size_factor'] = approx_sf
-    gid = st.group_id
-    m['approx_size_factor'] = {g: approx_sf[gid == i] for i, g in enumerate(m['groups'])}
-    m['size_factor'] = {g: size_factor[gid == i] for i, g in enumerate(m['groups'])}
+    # per-group views in the cells' original order: the count blocks' cell order is the stable sort by group (engine.plan_blocks)
+    order, ends = st.blocks.cell_order, np.cumsum(st.blocks.grp_ncells)
+    a_sorted, s_sorted = approx_sf[order], size_factor[order]
+    m['approx_size_factor'] = {g: a_sorted[ends[i] - st.blocks.grp_ncells[i]:ends[i]] for i, g in enumerate(m['groups'])}
+    m['size_factor'] = {g: s_sorted[ends[i] - st.blocks.grp_ncells[i]:ends[i]] for i, g in enumerate(m['groups'])}
 
 
 def get_groups(adata):
