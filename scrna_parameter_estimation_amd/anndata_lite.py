@@ -27,6 +27,7 @@ class AnnDataLite:
         if len(self.obs) != n or len(self.var) != g:
             raise ValueError("obs/var length does not match X")
         self.uns = uns if uns is not None else {}
+        self.device_csr = None      # engine.DeviceCSR already resident in HBM (h5ad.read_h5ad): setup_memento takes it instead of X
 
     @property
     def shape(self):

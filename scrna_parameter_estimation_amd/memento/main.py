@@ -144,6 +144,8 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
     m['num_bins'] = num_bins
 
     st = m['_hip'] = _HipState()
+    if device_csr is None:
+        device_csr = getattr(adata, 'device_csr', None)       # h5ad.read_h5ad(to_device=True) attaches the resident matrix
     st.csr = device_csr if device_csr is not None else engine.DeviceCSR(adata.X)
     st.comm = comm
     N, G = adata.shape
