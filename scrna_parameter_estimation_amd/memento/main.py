@@ -818,11 +818,12 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     (hypothesis_test.py:393-404): with ``strict=True`` the reference's two np.random.choice draws per pair are replayed from
     the global stream in pair order (exact agreement with the reference at num_cpus=1); otherwise the group /
     replicate-column assignments are drawn on the device (seeded by ``fill_seed``): statistically equivalent, not
-    draw-identical.  Without resample_rep the 2D path consumes the global stream exactly like the reference either way."""
+    draw-identical.  Without resample_rep the 2D path consumes the global stream exactly like the reference either way.
+    ``treatment_for_gene`` as the reference BEHAVES (main.py:492): a pair's treatment columns are looked up under
+    ``frozenset({name of the pair's first gene})`` -- the key is built from idx_1 twice -- and one number per pair is stored,
+    so the list must hold exactly one column (the reference raises ValueError on more); pinned by fixture ``api_tfg2d``."""
     if 'resampling' not in kwargs:
         raise TypeError("_compute_asl() missing 1 required positional argument: 'resampling'")
-    if treatment_for_gene is not None:
-        raise NotImplementedError("HIP path (2D): treatment_for_gene=None (the reference's own lookup is broken, main.py:492)")
     resampling = kwargs['resampling']
     resample_rep = bool(kwargs.get('resample_rep', False))
     approx = bool(kwargs.get('approx', False))
@@ -853,6 +854,14 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         first.append(c)
     first = np.asarray(first, dtype=np.int64)
     P_ = len(first)
+    tcol = np.zeros(P_, dtype=np.int64)                   # treatment column of every tested pair (column 0 without treatment_for_gene)
+    if treatment_for_gene is not None:
+        names2, trt_cols = np.asarray(adata.var.index), list(treatment.columns)
+        for k, c in enumerate(first):
+            cols = treatment_for_gene[frozenset({names2[int(idx1[c])]})]
+            if len(cols) != 1:
+                raise ValueError("setting an array element with a sequence.")          # what main.py:507 does with more columns
+            tcol[k] = trt_cols.index(cols[0])
     slot = {int(g): i for i, g in enumerate(st.cols_local)}
     c1 = np.array([slot[int(idx1[c])] for c in first], dtype=np.int64)
     c2 = np.array([slot[int(idx2[c])] for c in first], dtype=np.int64)
@@ -904,7 +913,8 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 r1a[idx], r1b[idx], r0[idx] = uu[0::3], uu[1::3], uu[2::3]
                 gd = lv & (K_orig[pi] >= 1)
                 n = int(gd.sum())
-                if n and not (trt[gd] == 1).mean() == 1:
+                t_pi = trt if treatment_for_gene is None else trt[:, [tcol[lo + pi]]]
+                if n and not (t_pi[gd] == 1).mean() == 1:
                     ra = np.random.choice(n, size=(n, num_boot))
                     ra[:, 0] = np.arange(n)
                     ba = np.random.choice(num_boot, (n, num_boot)) + 1
@@ -918,11 +928,12 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                to_dev_order(np.where(skip, np.nan, true_corr).reshape(-1)))
         good = bs.active.reshape(n_ch, ng)                # device order
         cache, rows = {}, []
+        tc = tcol[lo:hi][so]                               # device order
         for k in range(n_ch):
-            key = good[k].tobytes()
+            key = (good[k].tobytes(), int(tc[k]))
             W = cache.get(key)
             if W is None:
-                W = cache[key] = _design.weight_rows(cov, trt, Nc_list, good[k])[:1]
+                W = cache[key] = _design.weight_rows(cov, trt[:, [tc[k]]], Nc_list, good[k])[:1]
             rows.append(W)
         Wmat = np.concatenate(rows, axis=0) if rows else np.zeros((0, ng))
         coef, stt = bs.contract(np.arange(n_ch), Wmat, good)
@@ -931,10 +942,11 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             # branch (hypothesis_test.py:384-386) and is not resampled
             masks, pair_mask, tt_rows, rr_test, Ms = {}, np.zeros(n_ch, dtype=np.int32), [], np.zeros(n_ch, dtype=bool), []
             for k in range(n_ch):
-                key = good[k].tobytes()
+                key = (good[k].tobytes(), int(tc[k]))
                 if key not in masks:
-                    Mg, ttg = _design.residual_parts(cov, trt, Nc_list, good[k])
-                    masks[key] = (len(Ms), ttg[:1], bool(good[k].any() and (trt[good[k]] == 1).mean() == 1))
+                    t_k = trt if treatment_for_gene is None else trt[:, [tc[k]]]
+                    Mg, ttg = _design.residual_parts(cov, t_k, Nc_list, good[k])
+                    masks[key] = (len(Ms), ttg[:1], bool(good[k].any() and (t_k[good[k]] == 1).mean() == 1))
                     Ms.append(Mg)
                 pair_mask[k], ttg, allones = masks[key]
                 tt_rows.append(ttg)
@@ -959,6 +971,8 @@ def ht_2d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
             for cc in members[frozenset((int(idx1[c]), int(idx2[c])))]:
                 corr_coef[cc], corr_se[cc], corr_asl[cc] = stt[k, 0], stt[k, 1], pvals[k]
     m['2d_ht'] = {'treatment': treatment, 'covariate': covariate, 'corr_coef': corr_coef, 'corr_se': corr_se, 'corr_asl': corr_asl}
+    if treatment_for_gene is not None:
+        m['2d_ht']['treatment_for_gene'] = treatment_for_gene                      # main.py:513-514
     st.last_bootstrap2d = bs
     st.last_chunk2d = (bounds[-2], bounds[-1]) if P_ else (0, 0)                   # diagnostics / tests: pair range of the last chunk
     if not inplace:

@@ -39,6 +39,11 @@ def api_perm():
 
 
 @pytest.fixture(scope="session")
+def api_tfg2d():
+    return load_golden("api_tfg2d")
+
+
+@pytest.fixture(scope="session")
 def api_opts():
     return load_golden("api_opts")
 

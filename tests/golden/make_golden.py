@@ -262,6 +262,38 @@ def perm_case(name, num_boot, ht_seed):
     print(name, "genes", len(out["gene_list"]), "finite p", np.isfinite(out["ht_exact_mean_asl"]).sum())
 
 
+def tfg2d_case(name, num_boot, ht_seed):
+    """ht_2d_moments(treatment_for_gene=...) as the reference actually behaves (main.py:492): the treatment columns of a pair are
+    looked up under frozenset({name of the pair's FIRST gene}) -- the key is built from idx_1 twice -- and the result goes into a
+    scalar slot per pair, so exactly one column per first gene works.  Inputs = those of api_small, two treatment columns."""
+    adata = synth_adata(1600, 120, 0.12, 2, 2, 11, dtype=np.float64)          # == api_small
+    memento.setup_memento(adata, q_column="q")
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7)
+    m = adata.uns["memento"]
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == 1).astype(float), "rep": (gdf["rep"].astype(int) == 1).astype(float)}, index=gdf.index)
+    ref = np.load(os.path.join(HERE, "api_small.npz"))
+    names = adata.var.index.values
+    pairs = list(zip(names[ref["pair_idx1"]].tolist(), names[ref["pair_idx2"]].tolist()))
+    memento.compute_2d_moments(adata, pairs)
+    firsts = []
+    for a, _ in pairs:
+        if a not in firsts:
+            firsts.append(a)
+    tfg = {frozenset({a}): [["rep", "cond"][i % 2]] for i, a in enumerate(firsts)}
+    np.random.seed(ht_seed)
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, treatment_for_gene=tfg, num_boot=num_boot, num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=False)
+    out = {"num_boot": np.int64(num_boot), "ht_seed": np.int64(ht_seed), "first_genes": np.array(firsts),
+           "first_gene_column": np.array([tfg[frozenset({a})][0] for a in firsts])}
+    for k in ["corr_coef", "corr_se", "corr_asl"]:
+        out["ht2_" + k] = np.asarray(m["2d_ht"][k]).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "pairs", len(pairs), "finite", np.isfinite(out["ht2_corr_coef"]).sum(), out["first_gene_column"][:6])
+
+
 def regress2d_rr_case(name, seed):
     """_regress_2d with resample_rep=True (hypothesis_test.py:393-404) on synthetic replicate correlations: 6 groups
     (2 conditions x 3 replicates), intercept + numeric covariate, binary treatment."""
@@ -492,7 +524,8 @@ def guide_loop_case(name):
 
 if __name__ == "__main__":
     only = {"corrmat": lambda: corrmat_case("corrmat_negvar", seed=7), "rr16": lambda: rr16_case("api_rr16", seed=51, num_boot=300, two_d_pairs=10),
-            "c1": lambda: c1_case("api_c1"), "guides": lambda: guide_loop_case("guide_loop")}
+            "c1": lambda: c1_case("api_c1"), "guides": lambda: guide_loop_case("guide_loop"),
+            "tfg2d": lambda: tfg2d_case("api_tfg2d", num_boot=300, ht_seed=33)}
     if len(sys.argv) == 2 and sys.argv[1] in only:      # the round-2 fixtures (each reproducible on its own)
         only[sys.argv[1]]()
         sys.exit(0)

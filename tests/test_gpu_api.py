@@ -104,6 +104,41 @@ def test_ht_1d_permutation_resampling_matches_reference(api_small, api_perm, tag
         np.testing.assert_allclose(ht[k], gp[f"ht_{tag}_{k}"], rtol=1e-5, atol=1e-12, equal_nan=True, err_msg=k)
 
 
+def test_ht_2d_treatment_for_gene_matches_reference(api_small, api_tfg2d):
+    """ht_2d_moments(treatment_for_gene=...) as the reference behaves (main.py:492): columns looked up under the pair's FIRST gene,
+    one column per pair; fixture from the real reference with two treatment columns alternating over the first genes."""
+    import pandas as pd
+
+    g, gt = api_small, api_tfg2d
+    memento, adata = _run_to_moments(g)
+    names = np.asarray(adata.var.index)
+    pairs = list(zip(names[g["pair_idx1"]].tolist(), names[g["pair_idx2"]].tolist()))
+    memento.compute_2d_moments(adata, pairs)
+    cov, _ = _design(memento, adata, g)
+    gdf = memento.get_groups(adata)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == 1).astype(float), "rep": (gdf["rep"].astype(int) == 1).astype(float)}, index=gdf.index)
+    tfg = {frozenset({a}): [c] for a, c in zip(gt["first_genes"].tolist(), gt["first_gene_column"].tolist())}
+    np.random.seed(int(gt["ht_seed"]))
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, treatment_for_gene=tfg, num_boot=int(gt["num_boot"]), num_cpus=1, verbose=0,
+                          resampling="bootstrap", approx=False)
+    ht = adata.uns["memento"]["2d_ht"]
+    assert ht["treatment_for_gene"] is tfg
+    np.testing.assert_allclose(ht["corr_coef"], gt["ht2_corr_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(ht["corr_se"], gt["ht2_corr_se"], rtol=1e-8, equal_nan=True)
+    # Pair 5 (g37, g59) is TIE-PRONE: in ~11 of its 300 replicates the replicate correlations of all good groups are clipped to
+    # the same value, the replicate coefficient is 0 up to the last bit and sits exactly ON the threshold of the extreme count
+    # (null = -stat): whether such a replicate counts is decided by LAPACK round-off inside the reference's LinearRegression
+    # (+-1e-16), here by the fixed weight row.  Coefficient and SE agree to 1e-8; the p-value may differ by those ties / 301.
+    tie = np.zeros(len(ht["corr_asl"]), dtype=bool)
+    tie[5] = True
+    np.testing.assert_allclose(ht["corr_asl"][~tie], gt["ht2_corr_asl"][~tie], rtol=1e-5, equal_nan=True)
+    assert abs(ht["corr_asl"][5] - gt["ht2_corr_asl"][5]) <= 12 / 301
+    assert np.isfinite(ht["corr_coef"]).sum() >= 8
+    with pytest.raises(ValueError):                           # two columns for one pair: the reference cannot store them either
+        memento.ht_2d_moments(adata, covariate=cov, treatment=trt, treatment_for_gene={k: ["cond", "rep"] for k in tfg}, num_boot=50,
+                              num_cpus=1, verbose=0, resampling="bootstrap")
+
+
 def test_ht_2d_permutation_resampling_matches_reference(api_small, api_perm):
     g, gp = api_small, api_perm
     memento, adata = _run_to_moments(g)
