@@ -356,7 +356,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_sell_split_count(const int64_t *
 //       that lands on slot 3 of a group files the group for storing;
 //   P4  filed groups are read back (entries of earlier tiles from the gene's 4-slot carry) and stored, one dwordx4 each;
 //   P5  per gene: the open group moves to the carry, cur += n, mask cleared.
-// No entry is ever placed by arrival order: two ingests of one CSR give bit-identical count blocks, hence bit-identical fp64 sums.
+// No entry is ever placed by arrival order: two ingests of one CSR give every gene the same entries in the same order, hence
+// bit-identical fp64 sums (which lane a gene gets among genes of equal length is k_sell_layout's arrival-order tie-break).
 #ifdef INGEST_STAMPS
 __device__ unsigned long long g_ing[16];
 #define ING_ST(k)                                          \

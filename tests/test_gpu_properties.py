@@ -44,6 +44,40 @@ def test_ingest_conserves_counts(big):
     assert blocks.total_rows * 256 <= 1.06 * blocks.nnz_sel + 256 * blocks.n_blocks * blocks.n_slices
 
 
+def test_ingest_is_reproducible_and_cell_ordered_at_scale(big):
+    """Two ingests of one CSR: every gene holds the same entries in the same order (no entry is placed by arrival order; only WHICH
+    lane of a slice a gene gets among genes of equal length may differ -- mm_sell_layout breaks those ties by arrival, and no sum
+    depends on it), ascending in the cell index -- checked on 600 random (block, gene) runs of the full-size blocks."""
+    engine, torch, csr, gid, blocks, sf = big
+    again = engine.CountBlocks(csr, gid, blocks.n_groups)
+    assert blocks.ranged and again.ranged and blocks.total_rows == again.total_rows
+    np.testing.assert_array_equal(blocks.blk_cnt, again.blk_cnt)
+    assert torch.equal(blocks.slice_w, again.slice_w) and torch.equal(blocks.slice_ptr, again.slice_ptr)
+
+    def run_of(bl, b, g, n):
+        sl = int(bl.rank[b, g].item())
+        r0 = int(engine.host(bl.blk_base)[b]) + int(bl.slice_ptr[b, sl >> 6].item())
+        w = (n + 3) // 4
+        e = bl.ent[r0 * 256:(r0 + w) * 256].view(torch.int32).reshape(w, 64, 4)[:, sl & 63, :].reshape(-1)
+        return e[:n], e[n:]
+
+    rng = np.random.default_rng(9)
+    checked = 0
+    for _ in range(600):
+        b = int(rng.integers(blocks.n_blocks))
+        nz = np.flatnonzero(blocks.blk_cnt[b] > 0)
+        g = int(nz[rng.integers(len(nz))])
+        n = int(blocks.blk_cnt[b, g])
+        e1, pad1 = run_of(blocks, b, g, n)
+        e2, _ = run_of(again, b, g, n)
+        assert torch.equal(e1, e2) and bool((e1 != 0).all()) and bool((pad1 == 0).all())
+        cell = (e1 & 8191).long()
+        assert bool((cell[1:] > cell[:-1]).all())
+        checked += n
+    assert checked > 20_000
+    del again
+
+
 def test_moments_scaling_linearity_and_determinism(big):
     engine, torch, csr, gid, blocks, sf = big
     S, sumx, maxx = blocks.moments(1.0 / sf)

@@ -1,11 +1,11 @@
-"""cProfile of one C3 bench step (host side): where the ~0.15 s outside the replay kernel goes.  usage: python tools/step_cprofile.py"""
+"""cProfile of one C3 bench step (host side): where the ~0.15 s outside the replay kernel goes.  usage: python tools/step_cprofile.py [config]"""
 import cProfile, os, pstats, sys, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch, scipy.sparse as sp
 import bench
 from scrna_parameter_estimation_amd import AnnDataLite, engine, memento
 
-cfg = bench.CONFIGS["C3"]
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C3"]
 N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
 ng = cfg["n_cond"] * cfg["n_rep"]
 csr = bench.synth_device_csr(cfg, 20250117, torch)
