@@ -158,12 +158,48 @@ __global__ __launch_bounds__(1024) void k_sell_layout(const uint16_t *__restrict
     }
   }
   __syncthreads();
-  for (int g = tid; g < n_genes; g += nt) {
-    uint32_t L = cnt[g];
-    uint32_t s = atomicAdd(&start[L], 1u);  // ties broken by arrival; slot order is irrelevant downstream
-    rank[(int64_t)b * n_genes + g] = (int32_t)s;
-    perm[(int64_t)b * n_slices * 64 + s] = g;
-    len_by_rank[s] = (uint16_t)L;
+  // Placement in GENE ORDER, so that genes of equal length take their slots by ascending gene id: the whole layout (hence every
+  // count block, bit for bit) is a pure function of the counts.  Step 1, all waves: for every gene the number of genes with the
+  // same length among the LOWER lanes of its 64-gene chunk (64 readlanes; parked in the rank array).  Step 2, one wave walks the
+  // chunks in order: slot = running counter of the length + that number; the counters move on only after every lane of the
+  // chunk has read them (LDS operations of one wave complete in order).  Four chunks' operands are loaded ahead.
+  {
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int g0 = wave * 64; g0 < n_genes; g0 += nw * 64) {
+      int g = g0 + lane;
+      uint32_t L = g < n_genes ? (uint32_t)cnt[g] : 0xFFFFFFFFu, r = 0;
+      for (int i = 0; i < 64; i++) {
+        uint32_t Li = (uint32_t)__builtin_amdgcn_readlane((int)L, i);
+        r += (Li == L && i < lane) ? 1u : 0u;
+      }
+      if (g < n_genes) rank[(int64_t)b * n_genes + g] = (int32_t)r;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      for (int g0 = 0; g0 < n_genes; g0 += 256) {
+        uint32_t Lq[4], rq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          int g = g0 + 64 * q + lane;
+          Lq[q] = g < n_genes ? (uint32_t)cnt[g] : 0u;
+          rq[q] = g < n_genes ? (uint32_t)rank[(int64_t)b * n_genes + g] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          int g = g0 + 64 * q + lane;
+          uint32_t L = Lq[q];
+          if (g < n_genes) {
+            uint32_t sl = ((volatile uint32_t *)start)[L] + rq[q];
+            rank[(int64_t)b * n_genes + g] = (int32_t)sl;
+            perm[(int64_t)b * n_slices * 64 + sl] = g;
+            len_by_rank[sl] = (uint16_t)L;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (g < n_genes) atomicAdd(&start[L], 1u);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
   }
   for (int s = n_genes + tid; s < n_slices * 64; s += nt) perm[(int64_t)b * n_slices * 64 + s] = -1;
   __syncthreads();
@@ -357,7 +393,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_sell_split_count(const int64_t *
 //   P4  filed groups are read back (entries of earlier tiles from the gene's 4-slot carry) and stored, one dwordx4 each;
 //   P5  per gene: the open group moves to the carry, cur += n, mask cleared.
 // No entry is ever placed by arrival order: two ingests of one CSR give every gene the same entries in the same order, hence
-// bit-identical fp64 sums (which lane a gene gets among genes of equal length is k_sell_layout's arrival-order tie-break).
+// bit-identical fp64 sums; k_sell_layout breaks length ties by gene id, so the count blocks as a whole are bit-identical too.
 #ifdef INGEST_STAMPS
 __device__ unsigned long long g_ing[16];
 #define ING_ST(k)                                          \

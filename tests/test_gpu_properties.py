@@ -44,15 +44,20 @@ def test_ingest_conserves_counts(big):
     assert blocks.total_rows * 256 <= 1.06 * blocks.nnz_sel + 256 * blocks.n_blocks * blocks.n_slices
 
 
-def test_ingest_is_reproducible_and_cell_ordered_at_scale(big):
-    """Two ingests of one CSR: every gene holds the same entries in the same order (no entry is placed by arrival order; only WHICH
-    lane of a slice a gene gets among genes of equal length may differ -- mm_sell_layout breaks those ties by arrival, and no sum
-    depends on it), ascending in the cell index -- checked on 600 random (block, gene) runs of the full-size blocks."""
+def test_ingest_is_bit_identical_and_cell_ordered_at_scale(big):
+    """Two ingests of one CSR give the same count blocks bit for bit: no entry is placed by arrival order (row masks + popcount
+    ranks) and the layout breaks ties between genes of equal length by gene id.  Inside a gene the entries ascend in the cell
+    index -- checked on 600 random (block, gene) runs of the full-size blocks."""
     engine, torch, csr, gid, blocks, sf = big
     again = engine.CountBlocks(csr, gid, blocks.n_groups)
     assert blocks.ranged and again.ranged and blocks.total_rows == again.total_rows
     np.testing.assert_array_equal(blocks.blk_cnt, again.blk_cnt)
     assert torch.equal(blocks.slice_w, again.slice_w) and torch.equal(blocks.slice_ptr, again.slice_ptr)
+    assert torch.equal(blocks.rank, again.rank) and torch.equal(blocks.perm, again.perm) and torch.equal(blocks.ent, again.ent)
+    # ties by gene id: among genes of equal length in a block the ranks ascend with the gene id
+    rk, cn = engine.host(blocks.rank)[0], blocks.blk_cnt[0]
+    order = np.lexsort((np.arange(len(cn)), -cn.astype(np.int64)))
+    np.testing.assert_array_equal(rk[order], np.arange(len(cn)))
 
     def run_of(bl, b, g, n):
         sl = int(bl.rank[b, g].item())
