@@ -73,7 +73,8 @@ def test_rowsum(eng):
     np.testing.assert_array_equal(csr.rowsum(mask), np.asarray(X[:, mask].sum(axis=1)).ravel().astype(np.float64))
 
 
-@pytest.mark.parametrize("shape", [(3000, 300, 0.08, 5), (20000, 130, 0.3, 2), (500, 70, 0.02, 7), (9000, 64, 0.9, 1), (2500, 1100, 0.5, 2)])
+@pytest.mark.parametrize("shape", [(3000, 300, 0.08, 5), (20000, 130, 0.3, 2), (500, 70, 0.02, 7), (9000, 64, 0.9, 1), (2500, 1100, 0.5, 2), (700, 1024, 0.05, 2), (700, 2049, 0.03, 3),
+                                   (300, 1, 0.6, 1)])
 def test_ingest_roundtrip(eng, shape):
     n, g, dens, ngr = shape
     X, gid, ng, sf = _small_problem(seed=n, n=n, g=g, density=dens, ngroups=ngr)
