@@ -18,9 +18,96 @@ import scipy.stats as stats
 TAIL_SIZES = tuple(range(300, 50, -30))  # N_exec = 300, 270, ..., 60  (hypothesis_test.py:102-116)
 
 
+# ---- genextreme.fit, the same numbers for a fifth of the time -----------------------------------------------------------------
+# scipy's fit is Nelder-Mead (optimize.fmin) on rv_continuous._penalized_nnlf, ~300 evaluations of ~120 us each, most of it spent
+# in generic wrappers (_lazywhere, argsreduce, support masks built through np.where).  _fast_nnlf below is the SAME arithmetic in the
+# same order with the same primitives (scipy.special.log1p, np.exp, np.sum, np.log) for the one distribution needed here, so every
+# evaluation returns the same double, the simplex takes the same path and the fitted parameters are bit-identical -- checked against
+# scipy's own fit on the first tail every process sees (a mismatch, e.g. another scipy version, switches the fast path off) and in
+# tests/test_cpu_host.py on a few hundred tails.
+try:
+    import scipy.special as _sc
+    from scipy import optimize as _optimize
+    from scipy.stats import _continuous_distns as _cd
+    from scipy.stats import _distn_infrastructure as _di
+
+    _LOGXMAX, _XMIN = _di._LOGXMAX, _cd._XMIN
+    _FAST_FIT = {"state": "unchecked"}          # unchecked -> on | off
+except Exception:                               # private names moved: scipy's fit only
+    _FAST_FIT = {"state": "off"}
+
+
+def _fast_nnlf(theta, x):
+    """genextreme._penalized_nnlf(theta, x) (scipy/stats/_distn_infrastructure.py, _continuous_distns.py), bit for bit."""
+    c, loc, scale = theta[0], theta[1], theta[2]
+    if not np.isfinite(c) or scale <= 0:
+        return np.inf
+    z = (x - loc) / scale
+    n_log_scale = len(z) * np.log(scale)
+    if c > 0:                                   # support (_get_support): z <= 1 / c
+        keep = z <= 1.0 / np.maximum(c, _XMIN)
+    elif c < 0:                                 #                         z >= 1 / c
+        keep = 1.0 / np.minimum(c, -_XMIN) <= z
+    else:
+        keep = None
+    n_bad = 0
+    if keep is not None:
+        n_bad = z.size - np.count_nonzero(keep)
+        if n_bad > 0:
+            z = z[keep]
+    if c != 0:                                  # _logpdf / _loglogcdf
+        cx = c * z
+        logex2 = _sc.log1p(-cx)
+        logpex2 = logex2 / c
+    else:
+        cx = np.zeros_like(z)
+        logex2 = _sc.log1p(-cx)
+        logpex2 = -z
+    logpdf = -np.exp(logpex2) + logpex2 - logex2
+    edge = (cx == 1) | (cx == -np.inf)
+    if edge.any():
+        logpdf = np.where(edge, -np.inf, logpdf)
+    if c == 1:
+        logpdf = np.where(z == 1, 0.0, logpdf)
+    fin = np.isfinite(logpdf)                   # _sum_finite
+    nf = np.count_nonzero(fin)
+    if nf != logpdf.size:
+        n_bad += logpdf.size - nf
+        logpdf = logpdf[fin]
+    return -np.sum(logpdf) + n_bad * _LOGXMAX * 100 + n_log_scale
+
+
+def _fast_gev_fit(data):
+    """rv_continuous.fit for genextreme with the objective above (same start, same optimizer, same acceptance checks)."""
+    data = np.asarray(data)
+    if not np.isfinite(data).all():
+        raise ValueError("The data contains non-finite values.")
+    x0 = stats.genextreme._fitstart(data)
+    vals = _optimize.fmin(_fast_nnlf, x0, args=(np.ravel(data),), disp=0)
+    obj = _fast_nnlf(vals, data)
+    vals = tuple(vals)
+    if not (np.isfinite(vals[0]) and vals[2] > 0) or not np.isfinite(obj):
+        raise RuntimeError("genextreme fit did not converge to admissible parameters")
+    return vals
+
+
+def gev_fit(tail):
+    """stats.genextreme.fit(tail) -- through the lean objective once it has reproduced scipy's answer in this process."""
+    if _FAST_FIT["state"] == "on":
+        return _fast_gev_fit(tail)
+    ref = stats.genextreme.fit(tail)            # (raises what scipy raises)
+    if _FAST_FIT["state"] == "unchecked":
+        try:
+            same = tuple(_fast_gev_fit(tail)) == tuple(ref)
+        except Exception:
+            same = False
+        _FAST_FIT["state"] = "on" if same else "off"
+    return ref
+
+
 def _gev_tail(tail, at, upper):
     """Fit genextreme to ``tail``; return the tail area at ``at`` if the KS gate passes, else None."""
-    params = stats.genextreme.fit(tail)
+    params = gev_fit(tail)
     if stats.kstest(tail, "genextreme", args=params)[1] > 0.05:
         return stats.genextreme.sf(at, *params) if upper else stats.genextreme.cdf(at, *params)
     return None
