@@ -158,7 +158,9 @@ class DeviceCSR:
 def auto_max_rows(ld, arrays=2, fraction=0.4):
     """Rows of replicate buffers ([rows][ld] fp64, ``arrays`` of them plus one coefficient buffer) that fit in
     ``fraction`` of the currently free HBM."""
-    free, _ = _torch().cuda.mem_get_info()
+    torch = _torch()
+    free, _ = torch.cuda.mem_get_info()
+    free += max(0, torch.cuda.memory_reserved() - torch.cuda.memory_allocated())    # blocks the caching allocator holds but nobody uses
     return max(1024, int(free * fraction) // (int(ld) * 8 * (arrays + 1)))
 
 
