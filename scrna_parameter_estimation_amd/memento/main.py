@@ -679,8 +679,9 @@ def ht_1d_vs_control(adata, control, num_boot=10000, num_cpus=1, rng='replay', f
     true_rv = np.stack([m['1d_moments'][g][2] for g in groups])
     fit = m['mv_regressor'][groups[0]]
     G_all = len(st.gene_idx)
-    if max_rows is None:
-        max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
+    if max_rows is None:                       # (40 % of the free HBM: BASELINE configs[4] then runs in two chunks, the second reusing the
+        max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)   # first one's buffers; ONE 108 GB chunk is 1 s faster in a warm process but 1.6 s
+                                                                 # slower in a fresh one -- mapping fresh device memory costs ~30 ms per GB)
     chunk = max(1, int(max_rows) // max(1, ng))
     cols = {k: [] for k in ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')}
     bs = rows = None
