@@ -306,7 +306,7 @@ def main():
         _lib.call("mm_timer_destroy", timer)
 
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch)
+            cpu = cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch, last_seed=1000 + args.steps - 1)
 
     if rank == 0:
         value = n_tests / elapsed
@@ -348,24 +348,39 @@ def _cpu_init(shared):
 
 
 def _cpu_gene(job):
-    """One gene of the CPU baseline: its share of the moments pass + the oracle's _ht_1d (bootstrap, regression, ASL)."""
+    """One gene of the CPU baseline: its share of the moments pass + the oracle's _ht_1d (bootstrap, regression, ASL).
+    ``skip`` = uniforms the global np.random stream has handed out before this gene's first chain in the GPU run being
+    compared with (2 per live chain, gene-major): the oracle then orders its bins with the very hash uniforms the GPU used, so
+    its coefficients / standard errors / p-values are comparable value for value (returned beside the time)."""
     from oracle import memento_oracle as orc
 
-    col32, tm_g, trv_g, seed = job
+    col32, tm_g, trv_g, seed, skip = job
     c = _CPU
     col = col32.astype(np.float64)
     np.random.seed(seed)
+    if skip:
+        np.random.random(int(skip))
     t0 = time.time()
     for k in range(len(c["sel"])):          # moments part of the step for this gene (estimator.py:177-183)
         x = col[c["sel"][k]]
         w = 1.0 / c["sf"][c["sel"][k]]
         _ = ((x * w).sum(), (x * x * w * w).sum(), (x * w * w).sum())
-    orc.ht_1d_gene(tm_g, trv_g, [col[s] for s in c["sel"]], c["asf"], c["cov"], c["trt"], c["Nc"], c["num_boot"], c["fit"], c["gq"],
-                   resampling="bootstrap", approx=False)
-    return time.time() - t0
+    res = orc.ht_1d_gene(tm_g, trv_g, [col[s] for s in c["sel"]], c["asf"], c["cov"], c["trt"], c["Nc"], c["num_boot"], c["fit"], c["gq"],
+                         resampling="bootstrap", approx=False)
+    return time.time() - t0, [np.atleast_1d(np.asarray(r, dtype=np.float64)) for r in res]
 
 
-def cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch):
+def stream_skips(true_mean, true_rv):
+    """Per kept gene: how many uniforms of the global np.random stream ht_1d_moments (strict=False) has consumed before the
+    gene's first chain -- two per live (gene, group) pair, gene-major (memento/bootstrap.py:62, :65; hypothesis_test.py:167-171
+    decides which pairs are live).  ``true_mean`` / ``true_rv``: [n_groups][genes]."""
+    with np.errstate(invalid="ignore"):
+        live = ~(np.isnan(true_mean) | np.isnan(true_rv) | (true_mean == 0) | (true_rv < 0))
+    per_gene = live.sum(axis=0)
+    return 2 * (np.cumsum(per_gene) - per_gene)
+
+
+def cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch, last_seed):
     """The CPU oracle (numpy restatement pinned to the reference) on a bounded sample of genes of the same matrix:
     ``--cpu-baseline-cores`` worker processes (default: the host cores of one GPU's share, at most 16), one gene per task,
     for about ``--cpu-baseline-seconds`` of wall time."""
@@ -385,13 +400,18 @@ def cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch):
     shared = dict(sel=sel, sf=adata.obs["memento_size_factor"].values, asf=[m["all_approx_size_factor"][s] for s in sel],
                   gq=np.array([m["group_q"][g] for g in groups]), Nc=np.array([len(s) for s in sel], dtype=float), cov=cov.values,
                   trt=trt.values, num_boot=cfg["num_boot"], fit=m["mv_regressor"]["all"])
-    jobs = [(np.ascontiguousarray(cols[:, j]), tm[:, slot[g]], trv[:, slot[g]], 1000 + j) for j, g in enumerate(pick)]
+    # every sampled gene is run on the uniforms the GPU's LAST timed step gave it (seed and stream position), so the oracle's
+    # outputs can be compared with the GPU's value for value
+    skips = stream_skips(tm, trv)
+    jobs = [(np.ascontiguousarray(cols[:, j]), tm[:, slot[g]], trv[:, slot[g]], last_seed, int(skips[slot[g]])) for j, g in enumerate(pick)]
     done, busy = 0, 0.0
+    results = {}
     if cores == 1:
         _cpu_init(shared)
         t0 = time.time()
-        for job in jobs:
-            busy += _cpu_gene(job)
+        for j, job in enumerate(jobs):
+            dt_, results[j] = _cpu_gene(job)
+            busy += dt_
             done += 1
             if time.time() - t0 > args.cpu_baseline_seconds:
                 break
@@ -403,20 +423,46 @@ def cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch):
         with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn"), initializer=_cpu_init, initargs=(shared,)) as ex:
             list(ex.map(int, range(4 * cores)))                 # start all workers (imports, shared data) outside the timed region
             t0 = time.time()
-            it = iter(jobs)
-            pending = {ex.submit(_cpu_gene, j) for j in [next(it) for _ in range(min(cores, len(jobs)))]}
+            it = iter(enumerate(jobs))
+            pending = {}
+            for _ in range(min(cores, len(jobs))):
+                j, job = next(it)
+                pending[ex.submit(_cpu_gene, job)] = j
             while pending:
-                fin, pending = wait(pending, return_when=FIRST_COMPLETED)
+                fin, _ = wait(list(pending), return_when=FIRST_COMPLETED)
                 for f in fin:
-                    busy += f.result()
+                    j = pending.pop(f)
+                    dt_, results[j] = f.result()
+                    busy += dt_
                     done += 1
                     if time.time() - t0 < args.cpu_baseline_seconds:      # keep every worker busy until the budget is spent
                         nxt = next(it, None)
                         if nxt is not None:
-                            pending.add(ex.submit(_cpu_gene, nxt))
+                            pending[ex.submit(_cpu_gene, nxt[1])] = nxt[0]
             dt = time.time() - t0
+    # the oracle's outputs for the sampled genes against the GPU's last timed step (same matrix, same hash uniforms; genes
+    # with a device-refilled replicate are left out: there the timed mode is statistically, not numerically, the reference)
+    ht = m["1d_ht"]
+    refilled = state.refill_stats["gene_refilled"]
+    nt = trt.shape[1]
+    diffs = {k: 0.0 for k in ("mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl")}
+    compared = 0
+    for j, res in results.items():
+        gi = slot[pick[j]]
+        if refilled[gi]:
+            continue
+        compared += 1
+        for k, r in zip(diffs, res):
+            got, want = ht[k][gi * nt:(gi + 1) * nt], r * np.ones(nt)
+            ok = np.isfinite(want) | np.isfinite(got)
+            if ok.any():
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    d = np.abs(got[ok] - want[ok]) / np.maximum(np.abs(want[ok]), 1e-300)
+                diffs[k] = max(diffs[k], float(np.nan_to_num(d, nan=np.inf).max()))
     return {"value": round(done * trt.shape[1] / dt, 4), "unit": "gene-tests/s", "cores": cores, "kind": "port",
             "per_core": round(done * trt.shape[1] / max(busy, 1e-9), 4),
+            "genes_compared_with_gpu": compared, "max_rel_p_diff": max(diffs["mean_asl"], diffs["var_asl"]),
+            "max_rel_diff": {k: float(f"{v:.3g}") for k, v in diffs.items()},
             "sample": f"{done} genes x {ng} groups x {cfg['num_boot']} bootstraps of the same matrix, oracle/memento_oracle.py, "
                       f"{cores} worker processes, {dt:.1f} s wall"}
 

@@ -161,7 +161,11 @@ int mm_bins_count(uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xc
  *   pk = pix[k]/remaining_p  with pix = mult/N_g and remaining_p as numpy's random_multinomial updates it
  *        (replicate-independent), lq = log(1-p) as the inversion sampler needs it,
  *   v = count, a = 1/sf, b = 1/sf^2                                              (fp64 each).
+ * A pair may instead be given to the one-wave-per-chain kernel (mm_boot1d_chain): d_pair_slot[p] = MM_CHAIN_SLOT | row, and
+ * the kernel writes the same five values of bin k as one 8-double record {pk, lq, v, a, b, -, -, -} at d_pk + 8*(row + k)
+ * (the caller reserves that region behind the tile rows of the d_pk allocation).
  * d_status[0] |= 8 if two bins of a pair collide in code (np.unique would merge them). */
+#define MM_CHAIN_SLOT (1LL << 62)
 int mm_bins_order(const uint32_t *d_tab, const int64_t *d_tab_ptr, const int32_t *d_xcap, const int32_t *d_K,
                   const int64_t *d_pair_list, int64_t n_list /* pairs handled by this launch */,
                   int32_t big /* 0: K <= 1024 (one wave per pair); 1: K <= 8192 (512 threads per pair) */, int32_t n_groups,
@@ -187,11 +191,52 @@ int mm_debug_replay_arith(int32_t exact);
  * d_slot_nobs = N_g, d_slot_omq = 1 - q_g of the slot's group.
  * Writes mean_b / var_b to d_out_mean[row*ld + 1 + b], row = d_slot_row[slot]; K == 1 pairs get NaN rows.
  * d_w_dump (optional, NULL in production) receives the int32 weights [slot][k][b] with stride kmax_dump. */
+/* Optional argument of mm_boot1d_replay: tiles that are really chains of the one-wave-per-chain form (see mm_boot1d_chain, whose
+ * operand records, per-chain arrays and jump table these are).  d_tile_chain[tile] = chain index or -1; a flagged tile owns no
+ * bin rows (tile_ptr[t + 1] == tile_ptr[t]) and its wave runs the chain instead -- at the tile's place in the launch's dispatch
+ * order, which is what the host's packing arranges. */
+typedef struct mm_chain_tiles {
+  const int32_t *d_tile_chain;
+  const double *d_ops;
+  const int64_t *d_ch_base;
+  const int32_t *d_ch_K;
+  const double *d_ch_nobs, *d_ch_omq;
+  const int64_t *d_ch_row;
+  const uint64_t *d_jump;
+  int32_t *d_w_dump;
+  int32_t kmax_dump;
+} mm_chain_tiles;
 int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, const double *d_a, const double *d_b,
                      const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
                      const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
                      int32_t mean_only /* 1: estimator._mean_only_1p, replicates are [mean+1, 10] (estimator.py:188-204) */,
-                     int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream);
+                     int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump,
+                     int64_t co_resident_waves /* waves of mm_boot1d_chain launched beside this call (0 = none): with n_tiles they
+                                                  decide between the two- and the three-waves-per-SIMD build of the kernel */,
+                     const mm_chain_tiles *chains /* NULL = every tile is a tile */, void *stream);
+
+/* K6+K7 for LONG chains: one WAVE per (gene, group) chain instead of one lane.  A chain is one sequential PCG64 stream
+ * (memento/bootstrap.py:102 re-seeds PCG64(5) per pair), so nothing but the generator itself parallelises: the 64 lanes
+ * produce the next 64 outputs of the stream in one step (PCG64 is an LCG: state j steps on = A^j s + C_j; d_jump[lane] =
+ * {A^(lane+1) hi, lo, C_(lane+1) hi, lo} for the stream's increment) and the wave-uniform samplers consume them in order.
+ * Draws, replicate means and variances are bit-identical to mm_boot1d_replay's.  Operands: 8-double records written by
+ * mm_bins_order for MM_CHAIN_SLOT pairs; chain c reads records [d_ch_base[c], d_ch_base[c] + d_ch_K[c]) of d_ops, needs
+ * d_ch_K[c] >= 2, and writes row d_ch_row[c].  d_w_dump (optional) receives int32 weights [chain][k][b], stride kmax_dump. */
+int mm_boot1d_chain(const double *d_ops, const int64_t *d_ch_base, const int32_t *d_ch_K, const double *d_ch_nobs,
+                    const double *d_ch_omq, const int64_t *d_ch_row, int64_t n_chains, const uint64_t *d_jump /* [64][4] */,
+                    const uint64_t pcg_state[4], int32_t num_boot, int32_t mean_only, int64_t ld, double *d_out_mean,
+                    double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream);
+
+/* K6+K7, lane-ASYNCHRONOUS tiles: one lane per chain like mm_boot1d_replay, but every lane walks its own chain at its own pace
+ * (the draw is a small state machine, csrc/npy_rng.h: lane_begin / lane_inv / lane_att / ...; one pass of a wave runs each phase
+ * for the lanes that are in it), so no lane waits for the longest search, the unluckiest BTPE draw or the longest chain of its
+ * wave.  Slot s = 64 * wave + lane runs chain s: records [d_ch_base[s], d_ch_base[s] + d_ch_K[s]) of d_ops (the 8-double records
+ * mm_bins_order writes for MM_CHAIN_SLOT pairs), row d_ch_row[s]; d_ch_K[s] < 2 = unused lane.  Same draws and replicate moments
+ * as mm_boot1d_replay, bit for bit.  d_w_dump (optional): int32 weights [slot][k][b], stride kmax_dump. */
+int mm_boot1d_async(const double *d_ops, const int64_t *d_ch_base, const int32_t *d_ch_K, const double *d_ch_nobs,
+                    const double *d_ch_omq, const int64_t *d_ch_row, int64_t n_slots, const uint64_t pcg_state[4], int32_t num_boot,
+                    int32_t mean_only, int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump,
+                    void *stream);
 
 /* FAST mode of K6+K7: one lane = one replicate, one wave = 64 replicates of one pair; every (pair, replicate)
  * has its own PCG64 stream derived from (seed, row, replicate).  Same sampler code and moment arithmetic as the

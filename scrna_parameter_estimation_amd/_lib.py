@@ -23,6 +23,12 @@ class MementoHipError(RuntimeError):
     pass
 
 
+class ChainTiles(ctypes.Structure):
+    """include/memento_hip.h: mm_chain_tiles"""
+    _fields_ = [("d_tile_chain", c_void_p), ("d_ops", c_void_p), ("d_ch_base", c_void_p), ("d_ch_K", c_void_p), ("d_ch_nobs", c_void_p),
+                ("d_ch_omq", c_void_p), ("d_ch_row", c_void_p), ("d_jump", c_void_p), ("d_w_dump", c_void_p), ("kmax_dump", c_int32)]
+
+
 _SIGS = {
     "mm_version": ([], ctypes.c_int),
     "mm_device_count": ([], ctypes.c_int),
@@ -53,7 +59,11 @@ _SIGS = {
     "mm_bins_count": ([c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_bins_order": ([c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 13, ctypes.c_int),
     "mm_boot1d_replay": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
-                         c_void_p, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
+                         c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "mm_boot1d_chain": ([c_void_p] * 6 + [c_int64, c_void_p, ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
+                        c_void_p, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "mm_boot1d_async": ([c_void_p] * 6 + [c_int64, ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p,
+                        c_int32, c_void_p], ctypes.c_int),
     "mm_debug_wave_clock": ([c_void_p], ctypes.c_int),
     "mm_debug_replay_arith": ([c_int32], ctypes.c_int),
     "mm_boot1d_fast": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),

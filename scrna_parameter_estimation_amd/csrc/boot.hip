@@ -14,6 +14,25 @@
 #include "mm_common.h"
 #include "npy_rng.h"
 
+// Chains that run one per WAVE (below: chain_body, k_boot1d_chain).  The tile kernel takes them as well: a tile flagged in
+// ``tile_chain`` is such a chain, so that the host can put chain waves at chosen places of ONE launch's dispatch order.
+#define MM_CHAIN_CLOCK_OFF (1 << 18)   // engine.CHAIN_CLOCK_OFF: the chain waves' records in the mm_debug_wave_clock buffer
+struct ChainArgs {
+  const double *ops;           // 8-double operand records (mm_bins_order, MM_CHAIN_SLOT pairs)
+  const int64_t *base;         // [chain] first record
+  const int32_t *K;            // [chain] bins
+  const double *nobs, *omq;    // [chain] N_g, 1 - q_g
+  const int64_t *row;          // [chain] output row
+  const uint64_t *jump;        // [64][4] PCG64 jump constants
+  const int32_t *tile_chain;   // [tile] chain index or -1 (tile kernel only; may be NULL)
+  int32_t *w_dump;             // optional weights [chain][k][b]
+  int32_t kmax_dump;
+};
+template <bool FAST>
+__device__ __forceinline__ void chain_body(const ChainArgs &ca, int64_t ch, int lane, uint64_t st0, uint64_t st1, int32_t num_boot,
+                                           int32_t mean_only, int64_t ld, double *__restrict__ out_mean, double *__restrict__ out_var,
+                                           int64_t *__restrict__ wave_clock);
+
 #ifndef BOOT_MIN_WAVES
 #define BOOT_MIN_WAVES 2
 #endif
@@ -32,10 +51,19 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
                                                        uint64_t st2, uint64_t st3, int32_t num_boot, int32_t mean_only,
                                                        int64_t ld, double *__restrict__ out_mean, double *__restrict__ out_var,
                                                        int32_t *__restrict__ w_dump, int32_t kmax_dump,
-                                                       int64_t *__restrict__ wave_clock) {
+                                                       int64_t *__restrict__ wave_clock, ChainArgs ca) {
   int lane = mm_lane();
   int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (tile >= n_tiles) return;
+  if (ca.tile_chain) {                                  // this wave's "tile" may be a chain of the one-wave-per-chain form
+    int cidx = __builtin_amdgcn_readfirstlane(ca.tile_chain[tile]);
+    if (cidx >= 0) {
+      if (tile * 2 < n_tiles) __builtin_amdgcn_s_setprio(BOOT_SETPRIO);
+      chain_body<FAST>(ca, (int64_t)cidx, lane, st0, st1, num_boot, mean_only, ld, out_mean, out_var,
+                       wave_clock ? wave_clock + MM_CHAIN_CLOCK_OFF : nullptr);
+      return;
+    }
+  }
   int64_t t_start = wave_clock ? (int64_t)wall_clock64() : 0;
   // Two waves share a SIMD.  The host puts the long tiles in the first half of the grid (engine.pair_tiles) and pairs
   // each with a short one from the second half: the long tile is the critical path, so it is served first.
@@ -173,6 +201,327 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
     wave_clock[tile * 4 + 1] = (int64_t)wall_clock64();
     wave_clock[tile * 4 + 2] = (int64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: se / cu / simd / wave slot
     wave_clock[tile * 4 + 3] = (int64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CHAIN kernel: one WAVE per (gene, group) chain.  A chain is one sequential PCG64 stream, so a chain that sits alone in a
+// 64-wide tile of k_boot1d_replay leaves 63 lanes idle and still pays the per-lane (exec-masked) control flow of that kernel.
+// Here every value of the chain is wave-uniform -- operands come in through scalar loads, the samplers' branches are scalar
+// branches -- and the 64 lanes do the one thing that parallelises: the generator.  PCG64 is an LCG, so the state j steps on
+// is A^j * s + C_j (mod 2^128): lane j holds (A^(j+1), C_(j+1)) and one 128-bit multiply-add per lane produces the next 64
+// outputs of the stream at once; the samplers take them one by one with v_readlane.  Same draws, same replicate moments (bit
+// for bit) as k_boot1d_replay; the host sends the long chains here and packs the rest into tiles (engine.Bootstrap1D.run).
+namespace npyrng {
+__device__ __forceinline__ uint64_t wave_read64(uint64_t x, int lane) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+struct WaveRng {
+  uint64_t s_hi, s_lo;              // per lane: the state (lane + 1) steps after the batch's base state
+  double u;                         // per lane: the uniform that state yields
+  uint64_t a_hi, a_lo, c_hi, c_lo;  // per lane: A^(lane+1), C_(lane+1)
+  int pos;                          // wave-uniform: next lane to hand out
+  typedef int Mark;
+  __device__ __forceinline__ Mark mark() const { return pos; }
+  __device__ __forceinline__ void rewind(Mark m) { pos = m; }
+  __device__ __forceinline__ void fill(uint64_t b_hi, uint64_t b_lo) {   // b = wave-uniform base state
+    uint64_t lo = a_lo * b_lo;
+    uint64_t hi = __umul64hi(a_lo, b_lo) + a_hi * b_lo + a_lo * b_hi;
+    uint64_t nlo = lo + c_lo;
+    uint64_t nhi = hi + c_hi + (nlo < lo ? 1ULL : 0ULL);
+    s_lo = nlo;
+    s_hi = nhi;
+    uint64_t x = nhi ^ nlo;
+    unsigned rot = (unsigned)(nhi >> 58);
+    uint64_t out = (x >> rot) | (x << ((64u - rot) & 63u));
+    u = (double)(out >> 11) * (1.0 / 9007199254740992.0);
+    pos = 0;
+  }
+  __device__ __forceinline__ void refill() {   // continue behind the last uniform handed out
+    if (pos == 0) return;
+    uint64_t b_hi = wave_read64(s_hi, pos - 1), b_lo = wave_read64(s_lo, pos - 1);
+    fill(b_hi, b_lo);
+  }
+  __device__ __forceinline__ void reserve(int n) {
+    if (pos > 64 - n) refill();
+  }
+};
+
+__device__ __forceinline__ double pcg64_next_double(WaveRng &g) {
+  if (g.pos == 64) g.refill();
+  uint64_t bits = wave_read64((uint64_t)__double_as_longlong(g.u), g.pos);
+  g.pos++;
+  return __longlong_as_double((long long)bits);
+}
+}  // namespace npyrng
+
+#ifndef CHAIN_MIN_WAVES
+#define CHAIN_MIN_WAVES 3
+#endif
+#ifndef CHAIN_PRIO
+#define CHAIN_PRIO 3      // issue priority of a chain wave against the tile kernel's waves (first half of its grid: BOOT_SETPRIO = 2)
+#endif
+// Four chains (waves) per 256-thread workgroup and the register budget of the tile kernel's three-waves-per-SIMD build: a
+// workgroup of either kernel then takes the same resources, so the chain waves and the tile waves of one bootstrap are all
+// resident together however the dispatcher interleaves the two launches (64-thread workgroups with their own register / LDS
+// footprint fragmented the CUs: tile workgroups waited for seconds, measured in profiles/README.md).
+template <bool FAST>
+__device__ __forceinline__ void chain_body(const ChainArgs &ca, int64_t ch, int lane, uint64_t st0, uint64_t st1, int32_t num_boot,
+                                           int32_t mean_only, int64_t ld, double *__restrict__ out_mean, double *__restrict__ out_var,
+                                           int64_t *__restrict__ wave_clock) {
+  const double *__restrict__ ops = ca.ops;
+  const int64_t *__restrict__ ch_base = ca.base;
+  const uint64_t *__restrict__ jump = ca.jump;
+  int32_t *__restrict__ w_dump = ca.w_dump;
+  const int32_t kmax_dump = ca.kmax_dump;
+  int64_t t_start = wave_clock ? (int64_t)wall_clock64() : 0;
+  const int K = ca.K[ch];
+  const int64_t row = ca.row[ch];
+  const double nobs = ca.nobs[ch], omq = ca.omq[ch];
+  const int32_t n = (int32_t)nobs;
+  // wave-uniform addresses: the compiler reads the operand records with scalar loads, one bin ahead (staging them in LDS
+  // instead measured the same step time: the scalar cache / L2 round trip is already hidden behind the step)
+  const double *__restrict__ op = ops + ch_base[ch] * 8;      // [K][8]: pk, lq, v, a, b, (3 spare)
+  double *om = out_mean + row * ld + 1;
+  double *ov = out_var + row * ld + 1;
+  npyrng::WaveRng g;
+  g.a_hi = jump[lane * 4 + 0];
+  g.a_lo = jump[lane * 4 + 1];
+  g.c_hi = jump[lane * 4 + 2];
+  g.c_lo = jump[lane * 4 + 3];
+  g.fill(st0, st1);
+  double keep_m = 0.0, keep_v = 0.0;     // lane (r & 63) keeps replicate r until 64 of them go out as one coalesced store
+#ifdef BOOT_STAMPS
+  uint64_t st_n_inv = 0, st_c_inv = 0, st_n_bt = 0, st_c_bt = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  for (int r = 0; r < num_boot; r++) {
+    double M1 = 0.0, M2 = 0.0;
+    int32_t dn = n;
+    double c_pk = op[0], c_lq = op[1], c_v = op[2], c_a = op[3], c_b = op[4];
+    for (int k = 0; k < K - 1; k++) {
+      const double *nx = op + (int64_t)(k + 1) * 8;          // k + 1 <= K - 1: the last bin's v, a, b are read here
+      double n_pk = nx[0], n_lq = nx[1], n_v = nx[2], n_a = nx[3], n_b = nx[4];
+#ifdef BOOT_STAMPS   // diagnostic build (tools/chain_micro.py): shader cycles inside the sampler call, by sampler
+      uint64_t s0_, s1_;
+      const double pe_ = c_pk <= 0.5 ? c_pk : 1.0 - c_pk;
+      const bool inv_ = pe_ * (double)dn <= 30.0;
+      NPY_CLOCK(s0_);
+#endif
+      int32_t w = npyrng::binomial_pre<int32_t, FAST, true>(g, c_pk, c_lq, dn);
+#ifdef BOOT_STAMPS
+      NPY_CLOCK(s1_);
+      if (c_pk != 0.0) {
+        if (inv_) { st_n_inv++; st_c_inv += s1_ - s0_; } else { st_n_bt++; st_c_bt += s1_ - s0_; }
+      }
+#endif
+      dn -= w;
+      if (w_dump && lane == 0) w_dump[((int64_t)ch * kmax_dump + k) * num_boot + r] = w;
+      if (w != 0) {
+        double wd = (double)w;
+        M1 += (c_v * wd) * c_a;
+        M2 += ((c_v * c_v) * wd) * c_b - ((omq * c_v) * wd) * c_b;
+      }
+      c_pk = n_pk; c_lq = n_lq; c_v = n_v; c_a = n_a; c_b = n_b;
+      if (dn <= 0) break;                                      // numpy stops the chain here; nothing is left for later bins
+    }
+    if (dn > 0) {                                              // the loop ran to its end: c_* hold the last bin, which takes the rest
+      if (w_dump && lane == 0) w_dump[((int64_t)ch * kmax_dump + (K - 1)) * num_boot + r] = dn;
+      double wd = (double)dn;
+      M1 += (c_v * wd) * c_a;
+      M2 += ((c_v * c_v) * wd) * c_b - ((omq * c_v) * wd) * c_b;
+    }
+    double mean = M1 / nobs;
+    double var = M2 / nobs - mean * mean;
+    if (mean_only) {
+      mean = mean + 1;
+      var = 10.0;
+    }
+    if (lane == (r & 63)) {
+      keep_m = mean;
+      keep_v = var;
+    }
+    if ((r & 63) == 63 || r == num_boot - 1) {
+      int r0 = r & ~63;
+      if (r0 + lane <= r) {
+        om[r0 + lane] = keep_m;
+        ov[r0 + lane] = keep_v;
+      }
+    }
+  }
+  if (wave_clock && lane == 0) {   // 8 int64 per chain: start, end (100 MHz); the stamps build adds sampler calls / shader cycles
+    wave_clock[ch * 8 + 0] = t_start;
+    wave_clock[ch * 8 + 1] = (int64_t)wall_clock64();
+#ifdef BOOT_STAMPS
+    wave_clock[ch * 8 + 2] = (int64_t)st_n_inv;
+    wave_clock[ch * 8 + 3] = (int64_t)st_c_inv;
+    wave_clock[ch * 8 + 4] = (int64_t)st_n_bt;
+    wave_clock[ch * 8 + 5] = (int64_t)st_c_bt;
+    wave_clock[ch * 8 + 6] = (int64_t)(__builtin_amdgcn_s_memtime() - st_t0);
+#endif
+  }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, CHAIN_MIN_WAVES) void k_boot1d_chain(ChainArgs ca, int64_t n_chains, uint64_t st0, uint64_t st1,
+                                                       int32_t num_boot, int32_t mean_only, int64_t ld, double *__restrict__ out_mean,
+                                                       double *__restrict__ out_var, int64_t *__restrict__ wave_clock) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ch = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
+  if (ch >= n_chains) return;
+  __builtin_amdgcn_s_setprio(CHAIN_PRIO);
+  chain_body<FAST>(ca, ch, lane, st0, st1, num_boot, mean_only, ld, out_mean, out_var, wave_clock);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ASYNC tile kernel: one lane = one chain, like k_boot1d_replay, but the lanes of a wave are NOT in lock step.  Every lane
+// carries the state of its own draw (npyrng::LaneDraw) and its own position (replicate r, bin k); one pass of the wave runs a
+// fixed sequence of phases -- retire / start, <= 9 steps of the inversion search, one BTPE attempt, explicit product, squeeze,
+// exact redo -- each for the lanes that are in it, and a lane whose draw is done goes on to ITS next bin in the next pass whatever
+// its neighbours are doing.  No lane waits for the longest search, the unluckiest BTPE draw or the longest chain of its wave; a
+// lane's operands are the 8-double records of its chain (the mm_boot1d_chain layout), read one bin ahead.  Draws and replicate
+// moments are those of k_boot1d_replay bit for bit (same samplers, same arithmetic per draw, same accumulation order).
+#ifndef ASYNC_MIN_WAVES
+#define ASYNC_MIN_WAVES 2     // 64 chains per wave: the chains of a launch rarely fill two waves per SIMD; no register spills
+#endif
+struct BinOps {
+  double pk, lq, v, a, b;
+};
+__device__ __forceinline__ BinOps load_bin(const double *__restrict__ rec) {
+  BinOps o;
+  o.pk = rec[0];
+  o.lq = rec[1];
+  o.v = rec[2];
+  o.a = rec[3];
+  o.b = rec[4];
+  return o;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, ASYNC_MIN_WAVES) void k_boot1d_async(const double *__restrict__ ops, const int64_t *__restrict__ ch_base,
+                                                        const int32_t *__restrict__ ch_K, const double *__restrict__ ch_nobs,
+                                                        const double *__restrict__ ch_omq, const int64_t *__restrict__ ch_row,
+                                                        int64_t n_slots, uint64_t st0, uint64_t st1, uint64_t st2, uint64_t st3,
+                                                        int32_t num_boot, int32_t mean_only, int64_t ld, double *__restrict__ out_mean,
+                                                        double *__restrict__ out_var, int32_t *__restrict__ w_dump, int32_t kmax_dump,
+                                                        int64_t *__restrict__ wave_clock) {
+  using namespace npyrng;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t t_start = wave_clock ? (int64_t)wall_clock64() : 0;
+  int K = slot < n_slots ? ch_K[slot] : 0;
+  if (K < 2) K = 0;                                             // unused lane (K == 1 rows are NaN rows, written by the host)
+  const int64_t sl = K ? slot : 0;
+  const double nobs = ch_nobs[sl], omq = ch_omq[sl];
+  const int32_t n = (int32_t)nobs;
+  const double *__restrict__ rec = ops + ch_base[sl] * 8;      // [K][8]: pk, lq, v, a, b, (3 spare)
+  const int64_t row = ch_row[sl];
+  double *om = out_mean + row * ld + 1;
+  double *ov = out_var + row * ld + 1;
+  Pcg64 g{st0, st1, st2, st3};
+  LaneDraw D;
+  D.w = 0;
+  int32_t state = K ? LS_RESTART : LS_IDLE;
+  int32_t r = 0, k = 0, dn = n;
+  double M1 = 0.0, M2 = 0.0;
+  BinOps cur = load_bin(rec), nxt = load_bin(rec + (K ? 8 : 0));
+  int64_t passes = 0;
+#ifdef BOOT_STAMPS   // diagnostic build (tools/chain_sweep.py): shader cycles of a wave per phase of the pass
+  uint64_t ph_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t;
+#define ASYNC_STAMP(i) do { uint64_t t_; NPY_CLOCK(t_); ph_c[i] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define ASYNC_STAMP(i)
+#endif
+  while (__ballot(state != LS_IDLE)) {
+    passes++;
+#ifdef BOOT_STAMPS
+    NPY_CLOCK(ph_t);
+#endif
+    // ---- retire the finished draw; finish the replicate or move on to the next bin ----------------------------------------
+    if (state == LS_DONE) {
+      const int32_t w = D.w;
+      if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = w;
+      if (w != 0) {
+        double wd = (double)w;
+        M1 += (cur.v * wd) * cur.a;
+        M2 += ((cur.v * cur.v) * wd) * cur.b - ((omq * cur.v) * wd) * cur.b;
+      }
+      dn -= w;
+      k++;
+      cur = nxt;                                                 // record k
+      if (dn <= 0 || k == K - 1) {
+        if (dn > 0) {                                            // every bin but the last has drawn: the last one takes the rest
+          if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = dn;
+          double wd = (double)dn;
+          M1 += (cur.v * wd) * cur.a;
+          M2 += ((cur.v * cur.v) * wd) * cur.b - ((omq * cur.v) * wd) * cur.b;
+        }
+        double mean = M1 / nobs;
+        double var = M2 / nobs - mean * mean;
+        if (mean_only) {
+          mean = mean + 1;
+          var = 10.0;
+        }
+        om[r] = mean;
+        ov[r] = var;
+        r++;
+        if (r < num_boot) {
+          cur = load_bin(rec);                                   // in flight until the lane starts its next replicate (next pass)
+          nxt = load_bin(rec + 8);
+          state = LS_RESTART;
+        } else {
+          state = LS_IDLE;
+        }
+      } else {
+        nxt = load_bin(rec + (int64_t)(k + 1) * 8);              // k + 1 <= K - 1
+        state = LS_START;
+      }
+    } else if (state == LS_RESTART) {
+      M1 = 0.0;
+      M2 = 0.0;
+      dn = n;
+      k = 0;
+      state = LS_START;
+    }
+    ASYNC_STAMP(0);
+    // ---- the draw of bin k, phase by phase (csrc/npy_rng.h) ------------------------------------------------------------------
+    if (state == LS_START) {
+      if (FAST) {
+        state = lane_begin(D, g, cur.pk, cur.lq, dn);
+      } else {                                                   // mm_debug_replay_arith(1): numpy's arithmetic, draw by draw
+        D.w = binomial_pre<int32_t, false>(g, cur.pk, cur.lq, dn);
+        state = LS_DONE;
+      }
+    }
+    ASYNC_STAMP(1);
+    if (state == LS_INV) state = lane_inv(D);
+    ASYNC_STAMP(2);
+    if (state == LS_ATT) state = lane_att(D, g);
+    ASYNC_STAMP(3);
+    if (state == LS_EXPL) state = lane_expl(D);
+    ASYNC_STAMP(4);
+    // the rarer phases do not run on every pass: a lane in one of them waits a pass or a few, every other lane saves the time
+    // (squeeze / Stirling: ~3 % of the lanes, every second pass; the exact redo: ~0.3 % of the draws, every eighth pass)
+    if ((passes & 1) == 0) {
+      if (state == LS_SQZ) state = lane_sqz(D);
+    }
+    ASYNC_STAMP(5);
+    if ((passes & 7) == 0) {
+      if (state == LS_XINV) state = lane_xinv(D, g);
+      if (state == LS_XBT) state = lane_xbt(D, g);
+    }
+    ASYNC_STAMP(6);
+  }
+  if (wave_clock && mm_lane() == 0) {
+    int64_t wave = slot >> 6;
+    wave_clock[wave * 4 + 0] = t_start;
+    wave_clock[wave * 4 + 1] = (int64_t)wall_clock64();
+    wave_clock[wave * 4 + 2] = passes;
+    wave_clock[wave * 4 + 3] = 0;
+#ifdef BOOT_STAMPS
+    for (int i = 0; i < 7; i++) wave_clock[(1 << 19) + wave * 8 + i] = (int64_t)ph_c[i];
+#endif
   }
 }
 
@@ -421,18 +770,58 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
                      const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
                      const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
                      int32_t mean_only, int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump,
-                     void *stream) {
+                     int64_t co_resident_waves, const mm_chain_tiles *chains, void *stream) {
   MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
+  ChainArgs ca{};
+  if (chains) {
+    MM_ARG(chains->d_tile_chain && chains->d_ops && chains->d_ch_base && chains->d_ch_K && chains->d_ch_nobs && chains->d_ch_omq &&
+           chains->d_ch_row && chains->d_jump);
+    ca = ChainArgs{chains->d_ops, chains->d_ch_base, chains->d_ch_K, chains->d_ch_nobs, chains->d_ch_omq, chains->d_ch_row, chains->d_jump,
+                   chains->d_tile_chain, chains->d_w_dump, chains->kmax_dump};
+  }
   MM_ARG(d_out_mean && d_out_var && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
   MM_ARG(n_tiles < 2147483647LL);
   // 4 tiles per 256-thread workgroup: tiles t and t + 1024 (+-3) then meet on one SIMD, which engine.pair_tiles relies on
   // (one tile per workgroup was measured too: worse when everything is resident, a wash in the many-tile regime)
-  auto kern = n_tiles > 2048 ? (g_exact_arith ? k_boot1d_replay<3, false> : k_boot1d_replay<3, true>)
-                             : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false> : k_boot1d_replay<BOOT_MIN_WAVES, true>);
+  // the 168-VGPR build (three waves per SIMD) when this launch and the chain-kernel waves running beside it need more than two
+  // wave slots per SIMD; the two-wave build otherwise
+  auto kern = n_tiles + (co_resident_waves > 0 ? co_resident_waves : 0) > 2048
+                  ? (g_exact_arith ? k_boot1d_replay<3, false> : k_boot1d_replay<3, true>)
+                  : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false> : k_boot1d_replay<BOOT_MIN_WAVES, true>);
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
-                     pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock);
+                     pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock, ca);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_boot1d_chain(const double *d_ops, const int64_t *d_ch_base, const int32_t *d_ch_K, const double *d_ch_nobs,
+                    const double *d_ch_omq, const int64_t *d_ch_row, int64_t n_chains, const uint64_t *d_jump,
+                    const uint64_t pcg_state[4], int32_t num_boot, int32_t mean_only, int64_t ld, double *d_out_mean,
+                    double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, void *stream) {
+  MM_ARG(d_ops && d_ch_base && d_ch_K && d_ch_nobs && d_ch_omq && d_ch_row && d_jump && pcg_state && d_out_mean && d_out_var);
+  MM_ARG(n_chains >= 0 && n_chains < 2147483647LL && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_chains == 0) return MM_OK;
+  auto kern = g_exact_arith ? k_boot1d_chain<false> : k_boot1d_chain<true>;
+  ChainArgs ca{d_ops, d_ch_base, d_ch_K, d_ch_nobs, d_ch_omq, d_ch_row, d_jump, nullptr, d_w_dump, kmax_dump};
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_chains + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ca, n_chains, pcg_state[0], pcg_state[1],
+                     num_boot, mean_only, ld, d_out_mean, d_out_var, g_wave_clock ? g_wave_clock + MM_CHAIN_CLOCK_OFF : nullptr);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_boot1d_async(const double *d_ops, const int64_t *d_ch_base, const int32_t *d_ch_K, const double *d_ch_nobs,
+                    const double *d_ch_omq, const int64_t *d_ch_row, int64_t n_slots, const uint64_t pcg_state[4], int32_t num_boot,
+                    int32_t mean_only, int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump,
+                    void *stream) {
+  MM_ARG(d_ops && d_ch_base && d_ch_K && d_ch_nobs && d_ch_omq && d_ch_row && pcg_state && d_out_mean && d_out_var);
+  MM_ARG(n_slots >= 0 && n_slots < (1LL << 38) && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_slots == 0) return MM_OK;
+  auto kern = g_exact_arith ? k_boot1d_async<false> : k_boot1d_async<true>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_ops, d_ch_base, d_ch_K, d_ch_nobs,
+                     d_ch_omq, d_ch_row, n_slots, pcg_state[0], pcg_state[1], pcg_state[2], pcg_state[3], num_boot, mean_only, ld,
+                     d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -192,8 +192,11 @@ __global__ __launch_bounds__(NT) void k_bins_order(const uint32_t *__restrict__ 
       __syncthreads();
     }
   }
+  // slot = tile*64 + lane of the 64-wide tile layout, or MM_CHAIN_SLOT | row for a chain of the one-wave-per-chain kernel
+  // (mm_boot1d_chain): its operands go, bin by bin, into 8-double records at o_pk + 8*(row + k)
+  const bool chain = (slot & MM_CHAIN_SLOT) != 0;
   int64_t tile = slot >> 6, ln = slot & 63;
-  int64_t row0 = tile_ptr[tile];
+  int64_t row0 = chain ? (slot & (MM_CHAIN_SLOT - 1)) : tile_ptr[tile];
   double N = grp_ncells[grp];
   bool tie = false;
   for (int k = tid; k + 1 < K; k += NT)
@@ -213,6 +216,15 @@ __global__ __launch_bounds__(NT) void k_bins_order(const uint32_t *__restrict__ 
     uint32_t bin = pay[k] >> 19, x = pay[k] & ((1u << 19) - 1u);
     double sf = sf_table[bin];
     double pk = ((double)mult[k] / N) / code[k];
+    if (chain) {
+      double *rec = o_pk + (row0 + k) * 8;
+      rec[0] = pk;
+      rec[1] = npyrng::binomial_lq(pk);
+      rec[2] = (double)x;
+      rec[3] = 1.0 / sf;
+      rec[4] = 1.0 / (sf * sf);
+      continue;
+    }
     int64_t o = (row0 + k) * 64 + ln;
     o_pk[o] = pk;
     o_lq[o] = npyrng::binomial_lq(pk);

@@ -19,8 +19,10 @@
 
 #if defined(__HIPCC__)
 #define NPY_HD __host__ __device__ __forceinline__
+#define NPY_HDM __host__ __device__ __forceinline__
 #else
 #define NPY_HD static inline
+#define NPY_HDM inline
 #endif
 
 #if defined(__clang__)
@@ -42,6 +44,16 @@
 #define NPY_ST_PARAM
 #define NPY_ST(i)
 #endif
+// NPY_KEEP(tk, x, alt): x, written so that the compiler cannot move what is computed from it out of the attempt loop.  ``tk`` is a
+// condition that is true on every pass but that only the run time knows (attempt <= n; BTPE runs for n > 60 and gives up after 16
+// attempts), ``alt`` any other run-time value.  The guarded fast paths keep their rarely taken branches cheap for the common path
+// with it: the reciprocals, Stirling terms etc. that only such a branch needs would otherwise be hoisted in front of the loop and
+// computed ahead of every draw, although the loop usually runs once and leaves through the triangular region.  (An empty asm
+// statement would do the same but makes the value lane-dependent in the compiler's eyes, which the wave-uniform chain kernel of
+// csrc/boot.hip must avoid.)
+// Only the one-chain-per-wave kernel asks for it (template parameter LAZY): in a 64-wide tile some lane takes every branch on nearly
+// every step, and there hoisting the loop-invariant set-up out of the attempt loop is exactly right.
+#define NPY_KEEP(tk, x, alt) ((!LAZY || (tk)) ? (x) : (alt))
 #ifndef NPY_NOTE_FALLBACK
 #define NPY_NOTE_FALLBACK(which)   // host tests count how often the guarded fast paths defer to the exact arithmetic
 #endif
@@ -51,6 +63,13 @@ namespace npyrng {
 struct Pcg64 {
   uint64_t s_hi, s_lo;  // 128-bit LCG state
   uint64_t i_hi, i_lo;  // 128-bit increment (odd)
+  // generator interface the samplers are written against (the wave-cooperative generator of csrc/boot.hip implements it too):
+  // mark() / rewind() bracket a guarded fast path that may have to be redone on the same uniforms; reserve(n) promises that
+  // n uniforms can be taken after a mark() without invalidating it
+  struct Mark { uint64_t hi, lo; };
+  NPY_HDM Mark mark() const { return Mark{s_hi, s_lo}; }
+  NPY_HDM void rewind(const Mark &m) { s_hi = m.hi; s_lo = m.lo; }
+  NPY_HDM void reserve(int) {}
 };
 
 NPY_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
@@ -80,8 +99,8 @@ NPY_HD double pcg64_next_double(Pcg64 &g) {
 }
 
 // ---- binomial: inversion for n*p <= 30 -------------------------------------------------------
-template <typename Int>
-NPY_HD Int binomial_inversion(Pcg64 &g, Int n, double p) {
+template <typename Int, typename Gen>
+NPY_HD Int binomial_inversion(Gen &g, Int n, double p) {
   double q = 1.0 - p;
   double qn = exp((double)n * log(q));
   double np_ = (double)n * p;
@@ -112,8 +131,8 @@ NPY_HD double btpe_stirling(double x, double x2) {
 template <typename Int>
 NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q);
 
-template <typename Int>
-NPY_HD Int binomial_btpe(Pcg64 &g, Int n, double p) {
+template <typename Int, typename Gen>
+NPY_HD Int binomial_btpe(Gen &g, Int n, double p) {
   double r = p < 1.0 - p ? p : 1.0 - p;
   double q = 1.0 - r;
   double fm = (double)n * r + r;
@@ -201,8 +220,8 @@ NPY_HD double binomial_lq(double pk) {
 
 // ``U`` = the first uniform of this draw, already taken from the stream by the caller (the guarded fast path below looks at it
 // first); further uniforms are drawn only by numpy's restart rule.
-template <typename Int>
-NPY_HD Int binomial_inversion_pre(Pcg64 &g, Int n, double p, double lq, double U) {
+template <typename Int, typename Gen>
+NPY_HD Int binomial_inversion_pre(Gen &g, Int n, double p, double lq, double U) {
   double q = 1.0 - p;
   double qn = exp((double)n * lq);
   Int bound = -1;  // computed lazily: np + 10*sqrt(np*q+1) >= 10, so X <= min(n, 9) can never exceed it
@@ -300,29 +319,40 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
   float qf = 1.0f - pf;                       // p <= 0.5
   float s = pf * f_rcp(qf);
   float qn = f_exp((float)((double)n * lq));  // n*lq >= -1.39 n p >= about -42 for n*p <= 30 (p <= 0.5): inside the fp32 range
-  float npf = nf * pf;
-  // numpy restarts when X exceeds bound = min(n, np + 10 sqrt(npq + 1)); stay strictly below it (and below 60: longer searches
-  // are ~6 sigma events for n*p <= 30 and go to the exact path)
-  float capf = npf + 10.0f * f_sqrt(npf * qf + 1.0f) - 1.5f;
-  capf = capf < nf ? capf : nf;
-  capf = capf < 60.0f ? capf : 60.0f;
-  int32_t cap = (int32_t)capf;
   float Uf = (float)U, px = qn;
   int32_t X = 0;
 #ifdef NPY_ABLATE_INV_LOOP  // timing experiments only: wrong results
-  return (int32_t)(Uf > px) + (cap < 0);
+  return (int32_t)(Uf > px);
 #endif
-  // fully unrolled (cap <= 60): the step number is a compile-time constant, so 1/X and (float)X are literals and an iteration is
-  // five full-rate fp32 instructions (no conversion, no v_rcp_f32); lock-stepped lanes share the trip count anyway
+  // fully unrolled: the step number is a compile-time constant, so 1/X and (float)X are literals and an iteration is five
+  // full-rate fp32 instructions (no conversion, no v_rcp_f32); lock-stepped lanes share the trip count anyway.
+  // numpy restarts when X exceeds bound = min(n, np + 10 sqrt(npq + 1)) >= min(n, 10): the first nine steps can never reach it, so
+  // the bound (a square root) is only worked out by searches that get that far.
   const float nf1 = nf + 1.0f;
+  const int32_t cap9 = n < (Int)9 ? (int32_t)n : 9;
 #pragma unroll
-  for (int it = 1; it <= 60; it++) {
-    if (!(Uf > px) || it > cap) break;
+  for (int it = 1; it <= 9; it++) {
+    if (!(Uf > px) || it > cap9) break;
     X = it;
     Uf -= px;
     px = px * ((nf1 - (float)it) * s) * (1.0f / (float)it);
   }
-  bool ok = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);   // also false when the search stopped at the cap
+  if (X == 9 && Uf > px) {
+    // stay strictly below numpy's bound (and below 60: longer searches are ~6 sigma events for n*p <= 30 and go to the exact path)
+    float npf = nf * pf;
+    float capf = npf + 10.0f * f_sqrt(npf * qf + 1.0f) - 1.5f;
+    capf = capf < nf ? capf : nf;
+    capf = capf < 60.0f ? capf : 60.0f;
+    int32_t cap = (int32_t)capf;
+#pragma unroll
+    for (int it = 10; it <= 60; it++) {
+      if (!(Uf > px) || it > cap) break;
+      X = it;
+      Uf -= px;
+      px = px * ((nf1 - (float)it) * s) * (1.0f / (float)it);
+    }
+  }
+  bool ok = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);   // also false when the search stopped at a cap
   return ok ? X : -1;
 }
 
@@ -332,7 +362,7 @@ template <typename Int>
 NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q) {
   Int k = y > m ? y - m : m - y;
   if (k > 64 || m > (Int)8000000) return -1;      // (consecutive integers must be exact in fp32 for the running index below)
-  float s = (float)r * f_rcp((float)q);
+  float s = (float)r * f_rcp((float)q);           // (the caller passes q through NPY_KEEP: this set-up stays inside the branch)
   float aa = s * ((float)n + 1.0f);
   Int lo = m < y ? m : y;
   // P = prod (aa/i - s) = prod (aa - s i)/i as a quotient of two running products, both scaled by 1/m so that every factor is ~1:
@@ -357,43 +387,64 @@ NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q)
   return d > 0.0f ? 0 : 1;
 }
 
-// BTPE with numpy's decisions but cheaper arithmetic: the set-up quotients through d_rcp (fp64, a few ulp), the logarithms,
-// the explicit product and the Stirling bound in fp32, every comparison and every floor() guarded by a margin several times the
-// worst-case error of the cheaper arithmetic.  Returns the draw y >= 0, having consumed exactly the uniforms numpy consumes, or -1
-// when some decision fell inside its guard: the caller then restores the generator and runs binomial_btpe (numpy's arithmetic).
-template <typename Int>
-NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r NPY_ST_PARAM) {   // r = p <= 0.5
+// BTPE with numpy's decisions but cheaper arithmetic: the set-up quotients through d_rcp (fp64, a few ulp), the square root of the
+// set-up in fp32 when the floor() it feeds is not close to a step, the logarithms, the explicit product and the Stirling bound in
+// fp32; every comparison and every floor() guarded by a margin several times the worst-case error of the cheaper arithmetic.
+// Returns the draw y >= 0, having consumed exactly the uniforms numpy consumes, or -1 when some decision fell inside its guard:
+// the caller then rewinds the generator and runs binomial_btpe (numpy's arithmetic).
+// What only the rarer branches need (1/c, 1/p1, 1/nrq, the Stirling terms) is computed inside them, behind NPY_KEEP: three draws
+// in four are accepted in the triangular region on the first attempt and pay for the set-up of p1 .. p4 only.
+template <typename Int, bool LAZY = false, typename Gen>
+NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p <= 0.5
   const double q = 1.0 - r;
   const double fm = (double)n * r + r;
-  const Int m = (Int)floor(fm);
-  const double md = (double)m;
+  const double md = floor(fm);
+  const Int m = (Int)md;
   const double nrq = (double)n * r * q;
-  const double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;      // integers are decided in numpy's own arithmetic
+  // p1 = floor(2.195 sqrt(nrq) - 4.6 q) + 0.5: an integer, decided in numpy's own arithmetic unless the fp32 evaluation of the
+  // argument is clear of every integer (its error: ~3e-7 relative from the square root and the products)
+  double p1;
+  {
+    float t = 2.195f * f_sqrt((float)nrq) - 4.6f * (float)q;
+    float ft = floorf(t);
+    float gt = 2e-6f * t + 1e-4f;
+    if (t - ft > gt && ft + 1.0f - t > gt) {
+      p1 = (double)ft + 0.5;
+    } else {
+      p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+    }
+  }
   const double xm = md + 0.5, xl = xm - p1, xr = xm + p1;
   const double c = 0.134 + 20.5 * d_rcp(15.3 + md);
   double a = (fm - xl) * d_rcp(fm - xl * r);
   const double laml = a * (1.0 + a * 0.5);
   a = (xr - fm) * d_rcp(xr * q);
   const double lamr = a * (1.0 + a * 0.5);
-  const double rlaml = d_rcp(laml), rlamr = d_rcp(lamr), rc = d_rcp(c), rp1 = d_rcp(p1);
+  const double rlaml = d_rcp(laml), rlamr = d_rcp(lamr);
   const double p2 = p1 * (1.0 + 2.0 * c);
   const double p3 = p2 + c * rlaml;
   const double p4 = p3 + c * rlamr;
   const double gu = 1e-11 * p4;                                       // set-up values are within ~1e-15 (relative) of numpy's
-  const float rnrq = f_rcp((float)nrq);
   NPY_ST(0);
   for (int attempt = 0; attempt < 16; attempt++) {
+    const bool tk = (Int)attempt <= n;   // always true (see NPY_KEEP)
     double u = pcg64_next_double(g) * p4;
     double v = pcg64_next_double(g);
     NPY_ST(1);
     if (fabs(u - p1) < gu || fabs(u - p2) < gu || fabs(u - p3) < gu) return -1;
-    double x, gx;
     if (u <= p1) {                       // triangular region: accepted at once
-      x = xm - p1 * v + u;
-      gx = 1e-10 * (fabs(x) + 1.0);
-    } else if (u <= p2) {                // parallelogram
-      x = xl + (u - p1) * rc;
-      v = v * c + 1.0 - fabs(md - x + 0.5) * rp1;
+      double x = xm - p1 * v + u;
+      double fx = floor(x);
+      double gx = 1e-10 * (fabs(x) + 1.0);
+      if (x - fx < gx || fx + 1.0 - x < gx) return -1;
+      if (fx < 0.0 || fx > (double)n) return -1;    // cannot happen inside the central regions; be safe
+      return (Int)fx;
+    }
+    double x, gx;
+    if (u <= p2) {                       // parallelogram
+      const double c_ = NPY_KEEP(tk, c, r), p1_ = NPY_KEEP(tk, p1, r);
+      x = xl + (u - p1) * d_rcp(c_);
+      v = v * c + 1.0 - fabs(md - x + 0.5) * d_rcp(p1_);
       if (fabs(v - 1.0) < 1e-10) return -1;
       if (v > 1.0) continue;
       gx = 1e-10 * (fabs(x) + 1.0);
@@ -414,11 +465,10 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r NPY_ST_PARAM) {   // r =
       continue;                          // numpy: y < 0 (left tail) / y > n (right tail)
     }
     Int y = (Int)fx;
-    if (u <= p1) return y;
     Int k = y > m ? y - m : m - y;
     NPY_ST(3);
     if (!((k > 20) && ((double)k < nrq / 2.0 - 1))) {
-      int dec = btpe_explicit_fast<Int>(v, n, m, y, r, q);
+      int dec = btpe_explicit_fast<Int>(v, n, m, y, r, NPY_KEEP(tk, q, r));
       NPY_ST(4);
       if (dec < 0) return -1;
       if (dec == 0) continue;
@@ -429,6 +479,7 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r NPY_ST_PARAM) {   // r =
       if (v > -1e-11) return -1;
       return y;                          // numpy: log of a negative number is NaN, every comparison fails, the draw is accepted
     }
+    const float rnrq = f_rcp((float)NPY_KEEP(tk, nrq, r));
     float kf = (float)k;
     float rho = (kf * rnrq) * ((kf * (kf * 0.333333333f + 0.625f) + 0.16666666666666666f) * rnrq + 0.5f);
     float t = -(kf * kf) * 0.5f * rnrq;
@@ -449,7 +500,8 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r NPY_ST_PARAM) {   // r =
     float T1 = (float)xm * f_log1p_small(d1);
     float T2 = ((float)(n - m) + 0.5f) * f_log1p_small(d2);
     float T3 = (float)(y - m) * f_log1p_small(d3);
-    float bound = T1 + T2 + T3 + f_stirling((float)m + 1.0f) + f_stirling((float)(n - m) + 1.0f) + f_stirling(yf1) + f_stirling(wf);
+    const float mf1 = (float)NPY_KEEP(tk, m, y) + 1.0f, zf = (float)(n - NPY_KEEP(tk, m, y)) + 1.0f;
+    float bound = T1 + T2 + T3 + f_stirling(mf1) + f_stirling(zf) + f_stirling(yf1) + f_stirling(wf);
     float gb = 4e-6f * (fabsf(T1) + fabsf(T2) + fabsf(T3)) + 1e-5f * (1.0f + fabsf(A));
     NPY_ST(6);
     if (A > bound + gb) continue;
@@ -459,10 +511,330 @@ NPY_HD Int binomial_btpe_fast(Pcg64 &g, Int n, double r NPY_ST_PARAM) {   // r =
   return -1;
 }
 
+// ---- resumable form: one binomial draw as a small state machine ---------------------------------------------------------
+// The lane-per-chain tile kernel used to walk the 64 chains of a wave in lock step: every bin step ran the inversion sampler and
+// BTPE one after the other, each to completion, for whichever lanes needed it -- so every lane waited for the longest search,
+// the largest number of BTPE attempts and every rarely taken branch of its 63 neighbours (in-kernel stamps: a lane spends ~1.5k
+// of the ~8k cycles a 64-wide BTPE call takes in code of its own).  Chains are independent, though: nothing but the instruction
+// stream ties the lanes of a wave together.  The functions below cut a draw into PHASES -- start (classify, set up), <= 9 steps
+// of the inversion search, one BTPE attempt, the explicit product, the squeeze / Stirling test, the exact redo -- so that a kernel
+// can run a fixed sequence of phases per pass, each for the lanes that are in it, and let every lane move on to its next bin as
+// soon as ITS draw is done (csrc/boot.hip: k_boot1d_async).  The arithmetic, the guards and the fallback rule are those of
+// binomial_inversion_fast / binomial_btpe_fast above: the draw and the uniforms it consumes are numpy's in every case.
+enum LaneState : int32_t { LS_START = 0, LS_INV, LS_ATT, LS_EXPL, LS_SQZ, LS_XINV, LS_XBT, LS_DONE, LS_RESTART, LS_IDLE };
+
+struct LaneDraw {
+  int32_t n;                 // cells left when the draw starts
+  int32_t flip;              // pk > 0.5: the draw is n - binomial(n, 1 - pk)
+  int32_t w;                 // the finished draw (after the flip)
+  double p;                  // min(pk, 1 - pk)
+  // inversion search
+  double lq, U;              // log(1 - p); the draw's first uniform (the exact redo starts from it)
+  float Uf, px, s, nf1;
+  int32_t X, it, cap;
+  // BTPE
+  double p1, p2, p3, p4, xm, c, laml, lamr, nrq;
+  int32_t m, attempts;
+  uint64_t mk_hi, mk_lo;     // generator state at the start of the draw (the exact redo rewinds to it)
+  double v;                  // pending acceptance test: v and y of the current attempt
+  int32_t y;
+};
+
+// Phase START: classify the draw binomial(n, pk) and set its sampler up.  n > 0.
+template <typename Gen>
+NPY_HD int32_t lane_begin(LaneDraw &D, Gen &g, double pk, double lq, int32_t n) {
+  D.n = n;
+  if (pk == 0.0) {
+    D.w = 0;
+    return LS_DONE;
+  }
+  D.flip = !(pk <= 0.5);
+  const double p = D.flip ? 1.0 - pk : pk;
+  D.p = p;
+  if (p * (double)n <= 30.0) {
+    D.lq = lq;
+    D.U = pcg64_next_double(g);
+    float nf = (float)n, pf = (float)p;
+    float qf = 1.0f - pf;
+    D.s = pf * f_rcp(qf);
+    D.px = f_exp((float)((double)n * lq));
+    D.Uf = (float)D.U;
+    D.X = 0;
+    D.it = 1;
+    D.nf1 = nf + 1.0f;
+    D.cap = n < 9 ? n : 9;
+    return LS_INV;
+  }
+  // BTPE set-up, as in binomial_btpe_fast
+  const double r = p, q = 1.0 - r;
+  const double fm = (double)n * r + r;
+  const double md = floor(fm);
+  D.m = (int32_t)md;
+  const double nrq = (double)n * r * q;
+  D.nrq = nrq;
+  double p1;
+  {
+    float t = 2.195f * f_sqrt((float)nrq) - 4.6f * (float)q;
+    float ft = floorf(t);
+    float gt = 2e-6f * t + 1e-4f;
+    if (t - ft > gt && ft + 1.0f - t > gt) {
+      p1 = (double)ft + 0.5;
+    } else {
+      p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+    }
+  }
+  const double xm = md + 0.5, xl = xm - p1, xr = xm + p1;
+  const double c = 0.134 + 20.5 * d_rcp(15.3 + md);
+  double a = (fm - xl) * d_rcp(fm - xl * r);
+  const double laml = a * (1.0 + a * 0.5);
+  a = (xr - fm) * d_rcp(xr * q);
+  const double lamr = a * (1.0 + a * 0.5);
+  const double p2 = p1 * (1.0 + 2.0 * c);
+  const double p3 = p2 + c * d_rcp(laml);
+  D.p1 = p1;
+  D.p2 = p2;
+  D.p3 = p3;
+  D.p4 = p3 + c * d_rcp(lamr);
+  D.xm = xm;
+  D.c = c;
+  D.laml = laml;
+  D.lamr = lamr;
+  D.attempts = 0;
+  typename Gen::Mark mk = g.mark();
+  D.mk_hi = mk.hi;
+  D.mk_lo = mk.lo;
+  return LS_ATT;
+}
+
+NPY_HD int32_t lane_inv_finish(LaneDraw &D) {
+  bool ok = (D.px - D.Uf > NPY_INV_GUARD) && (D.X == 0 || D.Uf > NPY_INV_GUARD);   // also false when the search stopped at a cap
+  if (!ok) return LS_XINV;
+  D.w = D.flip ? D.n - D.X : D.X;
+  return LS_DONE;
+}
+
+// Phase INV: the next segment of the search -- steps 1..9 with literal reciprocals, then eight steps at a time.  Written without
+// branches: in a wave some lane nearly always walks the whole segment, so every lane computes all of it (the step factors ahead
+// of the running product, which is then one multiply per step) and keeps the values at which ITS search stopped.
+NPY_HD int32_t lane_inv(LaneDraw &D) {
+  float Uf = D.Uf, px = D.px;
+  const float s = D.s, nf1 = D.nf1;
+  int32_t X = D.X;
+  bool stopped = false;
+  if (D.it == 1) {
+    const int32_t cap9 = D.cap;
+    float f[9];
+#pragma unroll
+    for (int it = 1; it <= 9; it++) f[it - 1] = ((nf1 - (float)it) * s) * (1.0f / (float)it);
+#pragma unroll
+    for (int it = 1; it <= 9; it++) {
+      stopped = stopped || !(Uf > px) || it > cap9;
+      float Un = Uf - px, pn = px * f[it - 1];
+      X = stopped ? X : it;
+      Uf = stopped ? Uf : Un;
+      px = stopped ? px : pn;
+    }
+    D.Uf = Uf;
+    D.px = px;
+    D.X = X;
+    if (!(X == 9 && Uf > px)) return lane_inv_finish(D);
+    // the search goes on: now numpy's bound matters (see binomial_inversion_fast)
+    float nf = nf1 - 1.0f, pf = (float)D.p, qf = 1.0f - pf;
+    float npf = nf * pf;
+    float capf = npf + 10.0f * f_sqrt(npf * qf + 1.0f) - 1.5f;
+    capf = capf < nf ? capf : nf;
+    capf = capf < 60.0f ? capf : 60.0f;
+    D.cap = (int32_t)capf;
+    D.it = 10;
+    return LS_INV;
+  }
+  // later segments: eight steps per pass, the step number a run-time value; 1/it through the reciprocal instruction (<= 1 ulp
+  // against the correctly rounded literal of the first segment: one more rounding per step, well inside NPY_INV_GUARD)
+  const int32_t it0 = D.it;
+  const int32_t cap = D.cap;
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    float itf = (float)(it0 + j);
+    f[j] = ((nf1 - itf) * s) * f_rcp(itf);
+  }
+  int32_t it = it0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    stopped = stopped || !(Uf > px) || it > cap || it > 60;
+    float Un = Uf - px, pn = px * f[j];
+    X = stopped ? X : it;
+    Uf = stopped ? Uf : Un;
+    px = stopped ? px : pn;
+    it = stopped ? it : it + 1;
+  }
+  D.Uf = Uf;
+  D.px = px;
+  D.X = X;
+  D.it = it;
+  // not stopped after eight steps: go on in the next pass (a ninth test would read step it0 + 8's state, which is what D holds)
+  return stopped ? lane_inv_finish(D) : (int32_t)LS_INV;
+}
+
+// Phase XINV: the search in numpy's arithmetic, from the draw's first uniform.
+template <typename Gen>
+NPY_HD int32_t lane_xinv(LaneDraw &D, Gen &g) {
+  NPY_NOTE_FALLBACK(0);
+  int32_t X = binomial_inversion_pre<int32_t>(g, D.n, D.p, D.lq, D.U);
+  D.w = D.flip ? D.n - X : X;
+  return LS_DONE;
+}
+
+NPY_HD int32_t lane_bt_accept(LaneDraw &D, int32_t y) {
+  D.w = D.flip ? D.n - y : y;
+  return LS_DONE;
+}
+
+// Phase ATT: one BTPE attempt (two uniforms).  Accepted in the triangle -> LS_DONE; rejected -> LS_ATT (the next pass draws
+// again); otherwise the acceptance test that the candidate needs: LS_EXPL or LS_SQZ; a decision inside a guard -> LS_XBT.
+template <typename Gen>
+NPY_HD int32_t lane_att(LaneDraw &D, Gen &g) {
+  if (D.attempts >= 16) return LS_XBT;
+  D.attempts++;
+  const double p1 = D.p1, p2 = D.p2, p3 = D.p3, p4 = D.p4, xm = D.xm;
+  const int32_t n = D.n, m = D.m;
+  const double gu = 1e-11 * p4;
+  double u = pcg64_next_double(g) * p4;
+  double v = pcg64_next_double(g);
+  if (fabs(u - p1) < gu || fabs(u - p2) < gu || fabs(u - p3) < gu) return LS_XBT;
+  if (u <= p1) {                       // triangular region: accepted at once
+    double x = xm - p1 * v + u;
+    double fx = floor(x);
+    double gx = 1e-10 * (fabs(x) + 1.0);
+    if (x - fx < gx || fx + 1.0 - x < gx) return LS_XBT;
+    if (fx < 0.0 || fx > (double)n) return LS_XBT;
+    return lane_bt_accept(D, (int32_t)fx);
+  }
+  const double xl = xm - p1, xr = xm + p1;
+  double x, gx;
+  if (u <= p2) {                       // parallelogram
+    const double c = D.c;
+    x = xl + (u - p1) * d_rcp(c);
+    v = v * c + 1.0 - fabs((double)m - x + 0.5) * d_rcp(p1);
+    if (fabs(v - 1.0) < 1e-10) return LS_XBT;
+    if (v > 1.0) return LS_ATT;
+    gx = 1e-10 * (fabs(x) + 1.0);
+  } else {                             // exponential tails: fp32 logarithm
+    if (v == 0.0) return LS_ATT;
+    float lv = f_log((float)v);
+    bool left = u <= p3;
+    double lam = left ? D.laml : D.lamr;
+    double rl = d_rcp(lam);
+    x = left ? xl + (double)lv * rl : xr - (double)lv * rl;
+    gx = (2e-6 * fabs((double)lv) + 4e-7) * rl + 1e-10 * (fabs(x) + 1.0);
+    v = left ? v * (u - p2) * lam : v * (u - p3) * lam;
+  }
+  double fx = floor(x);
+  if (x - fx < gx || fx + 1.0 - x < gx) return LS_XBT;
+  if (fx < 0.0 || fx > (double)n) {
+    if (u <= p2) return LS_XBT;        // cannot happen inside the two central regions; be safe
+    return LS_ATT;                     // numpy: y < 0 (left tail) / y > n (right tail)
+  }
+  int32_t y = (int32_t)fx;
+  int32_t k = y > m ? y - m : m - y;
+  D.v = v;
+  D.y = y;
+  return (!((k > 20) && ((double)k < D.nrq / 2.0 - 1))) ? LS_EXPL : LS_SQZ;
+}
+
+// btpe_explicit_fast with the running products split over four independent accumulator pairs: a lone wave issues a dependent
+// instruction only every ~9 cycles, so four short chains finish in a third of the time of one long one.  Other rounding order,
+// same guard (the error of a product of <= 64 fp32 factors is far below NPY_F_GUARD in any order).
+NPY_HD int btpe_explicit_fast4(double v, int32_t n, int32_t m, int32_t y, double r, double q) {
+  int32_t k = y > m ? y - m : m - y;
+  if (k > 64 || m > 8000000) return -1;
+  float s = (float)r * f_rcp((float)q);
+  float aa = s * ((float)n + 1.0f);
+  int32_t lo = m < y ? m : y;
+  float ic = f_rcp((float)m + 0.5f);
+  float aa_c = aa * ic, s_c = s * ic;
+  float base = (float)lo;
+  float Pn0 = 1.0f, Pn1 = 1.0f, Pn2 = 1.0f, Pn3 = 1.0f, Pd0 = 1.0f, Pd1 = 1.0f, Pd2 = 1.0f, Pd3 = 1.0f;
+  for (int32_t i = 0; i < k; i += 4) {
+    float i0 = base + (float)(i + 1), i1 = i0 + 1.0f, i2 = i0 + 2.0f, i3 = i0 + 3.0f;
+    bool h1 = i + 1 < k, h2 = i + 2 < k, h3 = i + 3 < k;
+    Pn0 *= aa_c - s_c * i0;
+    Pd0 *= i0 * ic;
+    Pn1 *= h1 ? aa_c - s_c * i1 : 1.0f;
+    Pd1 *= h1 ? i1 * ic : 1.0f;
+    Pn2 *= h2 ? aa_c - s_c * i2 : 1.0f;
+    Pd2 *= h2 ? i2 * ic : 1.0f;
+    Pn3 *= h3 ? aa_c - s_c * i3 : 1.0f;
+    Pd3 *= h3 ? i3 * ic : 1.0f;
+  }
+  float P = ((Pn0 * Pn1) * (Pn2 * Pn3)) * f_rcp((Pd0 * Pd1) * (Pd2 * Pd3));
+  float vf = (float)v;
+  float a_ = m <= y ? vf : vf * P;
+  float b_ = m <= y ? P : 1.0f;
+  float d = a_ - b_;
+  float mag = fabsf(a_) > fabsf(b_) ? fabsf(a_) : fabsf(b_);
+  if (!(fabsf(d) > NPY_F_GUARD * mag)) return -1;
+  return d > 0.0f ? 0 : 1;
+}
+
+// Phase EXPL: explicit f(y)/f(m) against v.
+NPY_HD int32_t lane_expl(LaneDraw &D) {
+  int dec = btpe_explicit_fast4(D.v, D.n, D.m, D.y, D.p, 1.0 - D.p);
+  if (dec < 0) return LS_XBT;
+  if (dec == 0) return LS_ATT;
+  return lane_bt_accept(D, D.y);
+}
+
+// Phase SQZ: squeeze, then the Stirling-corrected bound.
+NPY_HD int32_t lane_sqz(LaneDraw &D) {
+  const double v = D.v, r = D.p, q = 1.0 - D.p, nrq = D.nrq, xm = D.xm;
+  const int32_t n = D.n, m = D.m, y = D.y;
+  const int32_t k = y > m ? y - m : m - y;
+  if (v < 1e-11) {
+    if (v > -1e-11) return LS_XBT;
+    return lane_bt_accept(D, y);       // numpy: log of a negative number is NaN, every comparison fails, the draw is accepted
+  }
+  const float rnrq = f_rcp((float)nrq);
+  float kf = (float)k;
+  float rho = (kf * rnrq) * ((kf * (kf * 0.333333333f + 0.625f) + 0.16666666666666666f) * rnrq + 0.5f);
+  float t = -(kf * kf) * 0.5f * rnrq;
+  float A = f_log((float)v);
+  float gs = 1e-5f * (1.0f + fabsf(A)) + 6e-6f * (fabsf(t) + rho);
+  float lo_ = t - rho, hi_ = t + rho;
+  if (A < lo_ - gs) return lane_bt_accept(D, y);
+  if (A > hi_ + gs) return LS_ATT;
+  if (A < lo_ + gs || A > hi_ - gs) return LS_XBT;
+  float yf1 = (float)y + 1.0f;                                        // x1
+  float d1 = (float)(m - y) * f_rcp(yf1);                             // f1/x1 - 1 = (m - y)/(y + 1)
+  float wf = (float)(n - y) + 1.0f;                                   // w
+  float d2 = (float)(y - m) * f_rcp(wf);                              // z/w - 1 = (y - m)/(n - y + 1)
+  double num3 = ((double)n + 2.0) * r - ((double)y + 1.0);            // w r - x1 q, without the cancellation
+  float d3 = (float)num3 * f_rcp(yf1 * (float)q);                     // w r/(x1 q) - 1
+  if (fabsf(d1) > 0.35f || fabsf(d2) > 0.35f || fabsf(d3) > 0.35f) return LS_XBT;
+  float T1 = (float)xm * f_log1p_small(d1);
+  float T2 = ((float)(n - m) + 0.5f) * f_log1p_small(d2);
+  float T3 = (float)(y - m) * f_log1p_small(d3);
+  float bound = T1 + T2 + T3 + f_stirling((float)m + 1.0f) + f_stirling((float)(n - m) + 1.0f) + f_stirling(yf1) + f_stirling(wf);
+  float gb = 4e-6f * (fabsf(T1) + fabsf(T2) + fabsf(T3)) + 1e-5f * (1.0f + fabsf(A));
+  if (A > bound + gb) return LS_ATT;
+  if (A < bound - gb) return lane_bt_accept(D, y);
+  return LS_XBT;
+}
+
+// Phase XBT: rewind the generator to the start of the draw and run numpy's BTPE.
+template <typename Gen>
+NPY_HD int32_t lane_xbt(LaneDraw &D, Gen &g) {
+  NPY_NOTE_FALLBACK(1);
+  typename Gen::Mark mk{D.mk_hi, D.mk_lo};
+  g.rewind(mk);
+  int32_t y = binomial_btpe<int32_t>(g, D.n, D.p);
+  return lane_bt_accept(D, y);
+}
+
 // binomial(pk, n) with lq = binomial_lq(pk) precomputed; identical draws to binomial(g, pk, n).  FAST selects the guarded
 // fp32 evaluation of the two search loops (same draws, fewer instructions); FAST = false is numpy's arithmetic throughout.
-template <typename Int, bool FAST = false>
-NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
+template <typename Int, bool FAST = false, bool LAZY = false, typename Gen>
+NPY_HD Int binomial_pre(Gen &g, double pk, double lq, Int n) {
   if (n == 0 || pk == 0.0) return 0;
   bool flip = !(pk <= 0.5);
   double p = flip ? 1.0 - pk : pk;
@@ -477,16 +849,17 @@ NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
     X = (Int)((double)n * p);
 #else
     if (FAST) {
-      Pcg64 saved = g;
+      g.reserve(34);                   // the fast path gives up after 16 attempts (2 uniforms each)
+      typename Gen::Mark saved = g.mark();
 #if defined(BOOT_STAMPS) && defined(__HIPCC__)
       uint64_t npy_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      X = binomial_btpe_fast<Int>(g, n, p, npy_dummy);
+      X = binomial_btpe_fast<Int, LAZY>(g, n, p, npy_dummy);
 #else
-      X = binomial_btpe_fast<Int>(g, n, p);
+      X = binomial_btpe_fast<Int, LAZY>(g, n, p);
 #endif
       if (X < 0) {
         NPY_NOTE_FALLBACK(1);
-        g = saved;
+        g.rewind(saved);
         X = binomial_btpe<Int>(g, n, p);
       }
     } else {
@@ -497,8 +870,8 @@ NPY_HD Int binomial_pre(Pcg64 &g, double pk, double lq, Int n) {
   return flip ? n - X : X;
 }
 
-template <typename Int>
-NPY_HD Int binomial(Pcg64 &g, double p, Int n) {
+template <typename Int, typename Gen>
+NPY_HD Int binomial(Gen &g, double p, Int n) {
   if (n == 0 || p == 0.0) return 0;
   if (p <= 0.5) {
     if (p * (double)n <= 30.0) return binomial_inversion<Int>(g, n, p);

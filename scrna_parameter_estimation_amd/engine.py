@@ -408,6 +408,21 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
     return _tiles_from_lanes(lanes, n_act)
 
 
+# Which chains run one per WAVE (mm_boot1d_chain: wave-uniform samplers, the 64 lanes produce the PCG64 stream in batches)
+# instead of one per lane of a tile.  CHAIN_LONE: every chain the packer leaves ALONE in its tile -- the long ones; a lone chain
+# steps in 0.75 us there against 0.96-1.2 us as the only lane of a tile wave.  CHAIN_MIN_K > 0: in addition every chain with at
+# least that many bins (tests / tools; 2 = all of them).  Both kernels replay the same draws, bit for bit.
+CHAIN_SLOT = 1 << 62      # include/memento_hip.h: MM_CHAIN_SLOT
+CHAIN_LONE = __import__('os').environ.get('MM_CHAIN_LONE', '1') != '0'        # (env overrides: measurement tools)
+CHAIN_MIN_K = int(__import__('os').environ.get('MM_CHAIN_MIN_K', '0'))
+# The other chains: TILE_MODE "async" = lane-asynchronous tile kernel (mm_boot1d_async: every lane walks its own chain at its
+# own pace, 64 chains of similar length per wave; chains with >= ASYNC_CHAIN_MIN_K bins go one per wave to mm_boot1d_chain);
+# "lockstep" = round 1-2's tile kernel (mm_boot1d_replay with the cost-model packing below; kept for A/B runs and the 2D path).
+TILE_MODE = __import__('os').environ.get('MM_TILE_MODE', 'lockstep')
+ASYNC_CHAIN_MIN_K = int(__import__('os').environ.get('MM_ASYNC_CHAIN_MIN_K', '160'))
+ASYNC_LANES = int(__import__('os').environ.get('MM_ASYNC_LANES', '64'))      # chains per wave of the async kernel (the other lanes idle)
+CHAIN_CLOCK_OFF = 1 << 18   # int64 offset of the chain kernel's records in the mm_debug_wave_clock buffer (tools/)
+
 PAIR_SLOTS = 1024      # SIMDs: tiles t and t + PAIR_SLOTS share one
 PAIR_TILES = True      # tools only: False = plain longest-first dispatch order
 
@@ -433,6 +448,33 @@ def pair_tiles(slot_of, n_tiles, K_of):
     new_id = np.empty(n_tiles, dtype=np.int64)
     new_id[new_order] = np.arange(n_tiles)
     return new_id[tile] * 64 + slot_of % 64
+
+
+_PCG_MULT = 0x2360ED051FC65DA44385DF649FCCF645
+_JUMP_CACHE = {}
+_SIDE_STREAM = []
+
+
+def pcg64_jump_table(seed=5):
+    """Device table [64][4] uint64 for mm_boot1d_chain: row j = (A^(j+1) hi, lo, C_(j+1) hi, lo) with
+    state_(i+j+1) = A^(j+1) * state_i + C_(j+1) (mod 2^128) for np.random.PCG64(seed)'s increment."""
+    if seed not in _JUMP_CACHE:
+        inc = np.random.PCG64(seed).state["state"]["inc"]
+        m64, M = (1 << 64) - 1, 1 << 128
+        a, c, rows = 1, 0, []
+        for _ in range(64):
+            a = (a * _PCG_MULT) % M
+            c = (c * _PCG_MULT + inc) % M
+            rows.append([a >> 64, a & m64, c >> 64, c & m64])
+        _JUMP_CACHE[seed] = dev(np.array(rows, dtype=np.uint64))
+    return _JUMP_CACHE[seed]
+
+
+def side_stream():
+    """A second HIP stream (torch plumbing) on which the chain kernel runs beside the tile kernel."""
+    if not _SIDE_STREAM:
+        _SIDE_STREAM.append(_torch().cuda.Stream())
+    return _SIDE_STREAM[0]
 
 
 def pcg64_state(seed=5):
@@ -516,9 +558,24 @@ class Bootstrap1D:
         with np.errstate(divide="ignore", invalid="ignore"):
             lq = np.log(1.0 - peff)
         sf = self.sf_table[bi]
+        if slot & CHAIN_SLOT:      # 8-double records of the chain kernel, addressed from the start of ops[0]'s allocation
+            rec = np.zeros((len(pk), 8))
+            rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4] = pk, lq, xi, 1.0 / sf, 1.0 / (sf * sf)
+            r0_ = (slot & (CHAIN_SLOT - 1)) * 8
+            self._opsbuf[r0_:r0_ + rec.size] = dev(rec.reshape(-1))
+            return
         idx = dev((int(tile_ptr[slot >> 6]) + np.arange(len(pk), dtype=np.int64)) * 64 + (slot & 63))
         for arr, vals in zip(ops, (pk, lq, xi, 1.0 / sf, 1.0 / (sf * sf))):
             arr[idx] = dev(vals)
+
+    def weights_of(self, p):
+        """Test helper (after run(dump_weights=True)): the int32 multinomial weights [K][B] of pair p, whichever kernel drew them."""
+        K = int(self.K[p])
+        if self.async_index[p] >= 0:
+            return host(self.w_dump_async[int(self.async_slot[self.async_index[p]]), :K, :])
+        if self.pair_slot[p] & CHAIN_SLOT:
+            return host(self.w_dump_chain[int(self.chain_index[p]), :K, :])
+        return host(self.w_dump[int(self.pair_slot[p]), :K, :])
 
     def alloc_outputs(self, true_mean_log, true_rv_log):
         """ym/yv [n_pairs][B+1] = NaN, column 0 = log true mean / log true residual variance (hypothesis_test.py:174)."""
@@ -541,13 +598,37 @@ class Bootstrap1D:
         active = (~np.asarray(skip, dtype=bool)) & (self.K >= 2)
         active[:first_pair] = False
         act = np.flatnonzero(active)
-        order = act[np.argsort(-self.K[act], kind="stable")]
-        n_act = len(order)
+        order_all = act[np.argsort(-self.K[act], kind="stable")]
+        # the longest chains run one per wave (mm_boot1d_chain), the others one per lane of a tile (mm_boot1d_replay)
+        n_chain = 0 if (fast or not CHAIN_MIN_K) else int(np.searchsorted(-self.K[order_all], -CHAIN_MIN_K, side="right"))
+        use_async = TILE_MODE == "async" and not fast and target_waves is None
+        if use_async and ASYNC_CHAIN_MIN_K:
+            n_chain = max(n_chain, int(np.searchsorted(-self.K[order_all], -ASYNC_CHAIN_MIN_K, side="right")))
+        chain_pairs, order = order_all[:n_chain], order_all[n_chain:]
+        async_pairs = order if use_async else order[:0]           # K descending: the 64 chains of a wave have similar lengths
+        if use_async:
+            order = order[:0]
+        n_async = len(async_pairs)
         # replay: cost-model lane packing (one lane = one sequential chain); fast: dense 64-wide tiles (one WAVE per pair)
         slot_of, n_tiles = pack_lanes(self.K[order], PACK_WAVES if target_waves is None else target_waves, dense=fast)
         if not fast:
             slot_of = pair_tiles(slot_of, n_tiles, self.K[order])
-        self.n_tiles = n_tiles
+        n_launch = n_chain                    # chains of the separate mm_boot1d_chain launch (CHAIN_MIN_K / ASYNC_CHAIN_MIN_K rules)
+        tile_chain = None
+        if CHAIN_LONE and not fast and n_tiles:
+            # A chain the packer left alone in its tile takes a whole wave either way: that wave runs it in the wave-uniform
+            # form (chain_body inside the tile kernel), at the tile's place in the dispatch order -- the packing and pairing
+            # above stay what they are, the lone waves just step faster.
+            tile = slot_of // 64
+            lone = np.bincount(tile, minlength=n_tiles)[tile] == 1
+            if lone.any():
+                tile_chain = np.full(n_tiles, -1, dtype=np.int32)
+                tile_chain[tile[lone]] = n_chain + np.arange(int(lone.sum()))
+                chain_pairs = np.concatenate([chain_pairs, order[lone]])
+                n_chain = len(chain_pairs)
+                order, slot_of = order[~lone], slot_of[~lone]
+        n_act = len(order)
+        self.n_tiles, self.n_chain, self.n_async, self.n_chain_launch = n_tiles, n_chain, n_async, n_launch
         pair_slot = np.full(self.n_pairs, -1, dtype=np.int64)
         pair_slot[order] = slot_of
         slot_pair = np.full(n_tiles * 64, -1, dtype=np.int64)
@@ -557,15 +638,28 @@ class Bootstrap1D:
         tile_k = slot_K.reshape(n_tiles, 64).max(axis=1) if n_tiles else np.zeros(0, dtype=np.int32)
         tile_ptr = np.concatenate([[0], np.cumsum(tile_k.astype(np.int64))]).astype(np.int64)
         rows = int(tile_ptr[-1])
-        self.draws_per_replicate = int(np.maximum(self.K[order] - 1, 0).sum())
-        ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(5)]
+        self.draws_per_replicate = int(np.maximum(self.K[order_all] - 1, 0).sum())
+        # one allocation: five [rows][64] operand planes of the tiles, then the chains' 8-double records
+        plane = max(1, rows) * 64
+        rec_pairs = np.concatenate([chain_pairs, async_pairs])      # chains whose operands are 8-double records
+        rec_K = self.K[rec_pairs].astype(np.int64)
+        rec_base = np.concatenate([[0], np.cumsum(rec_K)]).astype(np.int64)
+        ch_K, ch_base = rec_K[:n_chain], rec_base[:n_chain + 1]
+        self._opsbuf = empty((5 * plane + 8 * max(1, int(rec_base[-1])),), torch.float64)
+        ops = [self._opsbuf[i * plane:(i + 1) * plane] for i in range(5)]
+        pair_slot[rec_pairs] = CHAIN_SLOT | (5 * plane // 8 + rec_base[:-1])
+        self.chain_index = np.full(self.n_pairs, -1, dtype=np.int64)
+        self.chain_index[chain_pairs] = np.arange(n_chain)
+        self.async_index = np.full(self.n_pairs, -1, dtype=np.int64)
+        self.async_index[async_pairs] = np.arange(n_async)
+        self.chain_pairs, self.async_pairs = chain_pairs, async_pairs
         d_pair_slot, d_tile_ptr = dev(pair_slot), dev(tile_ptr)
         status = zeros((1,), torch.int32)
         d_r1, d_r0 = dev(np.asarray(r1, dtype=np.float64)), dev(np.asarray(r0, dtype=np.float64))
         d_sf, d_nc = dev(self.sf_table), dev(self.blocks.grp_ncells.astype(np.float64))
-        small = order[self.K[order] <= ORDER_SMALL_CAP]
-        big = order[(self.K[order] > ORDER_SMALL_CAP) & (self.K[order] <= ORDER_BIG_CAP)]
-        huge = order[self.K[order] > ORDER_BIG_CAP]
+        small = order_all[self.K[order_all] <= ORDER_SMALL_CAP]
+        big = order_all[(self.K[order_all] > ORDER_SMALL_CAP) & (self.K[order_all] <= ORDER_BIG_CAP)]
+        huge = order_all[self.K[order_all] > ORDER_BIG_CAP]
         for lst, is_big in ((small, 0), (big, 1)):
             if len(lst):
                 d_lst = dev(lst)
@@ -584,12 +678,57 @@ class Bootstrap1D:
         self.slot_pair, self.slot_K, self.pair_slot, self.tile_ptr = slot_pair, slot_K, pair_slot, tile_ptr
         self._ops, self._nobs = ops, nobs          # kept for diagnostics (tools/replay_balance.py)
         d_slot_K, d_nobs, d_omq, d_slot_pair = dev(slot_K), dev(nobs), dev(omq), dev(slot_pair)
+        self.w_dump_chain = None
+        chain_tiles = None
+        if n_chain:
+            kd = int(ch_K.max()) if dump_weights else 0
+            self.w_dump_chain = zeros((n_chain, kd, B), torch.int32) if dump_weights else None
+            d_chb, d_chK = dev(ch_base[:-1]), dev(ch_K.astype(np.int32))
+            d_chn, d_cho = dev(self.blocks.grp_ncells[chain_pairs % ng].astype(np.float64)), dev(1.0 - self.grp_q[chain_pairs % ng])
+            d_chr = dev(chain_pairs.astype(np.int64))
+            d_recs = c_void_p(self._opsbuf.data_ptr() + 5 * plane * 8)
+            if tile_chain is not None:          # chains that run as waves of the tile kernel's own launch
+                d_tc = dev(tile_chain)
+                chain_tiles = _lib.ChainTiles(P(d_tc), d_recs, P(d_chb), P(d_chK), P(d_chn), P(d_cho), P(d_chr), P(pcg64_jump_table(pcg_seed)),
+                                              P(self.w_dump_chain), kd)
+        if n_launch:
+            # the chain kernel goes out first, on its own stream, and runs beside the tile kernel; the launch stream waits for
+            # it before the fill / log pass
+            side, main = side_stream(), torch.cuda.current_stream()
+            side.wait_stream(main)
+            _lib.call("mm_boot1d_chain", d_recs, P(d_chb), P(d_chK), P(d_chn), P(d_cho), P(d_chr),
+                      n_launch, P(pcg64_jump_table(pcg_seed)), pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv),
+                      P(self.w_dump_chain), kd, c_void_p(side.cuda_stream))
+        self.w_dump_async = None
+        if n_async:
+            ka = int(rec_K[n_chain:].max()) if dump_weights else 0
+            # slot = 64 * wave + lane; a wave takes ASYNC_LANES consecutive chains of the K-descending list, its other lanes idle
+            L = max(1, min(64, int(ASYNC_LANES)))
+            idx = np.arange(n_async)
+            a_slot = (idx // L) * 64 + idx % L
+            n_slots = int(a_slot[-1]) + 1
+            self.async_slot = a_slot
+
+            def spread(vals, dtype):
+                out = np.zeros(n_slots, dtype=dtype)
+                out[a_slot] = vals
+                return dev(out)
+
+            self.w_dump_async = zeros((n_slots, ka, B), torch.int32) if dump_weights else None
+            d_ab, d_aK = spread(rec_base[n_chain:-1], np.int64), spread(rec_K[n_chain:], np.int32)
+            d_an, d_ao = spread(self.blocks.grp_ncells[async_pairs % ng], np.float64), spread(1.0 - self.grp_q[async_pairs % ng], np.float64)
+            d_ar = spread(async_pairs, np.int64)
+            _lib.call("mm_boot1d_async", c_void_p(self._opsbuf.data_ptr() + 5 * plane * 8), P(d_ab), P(d_aK), P(d_an), P(d_ao), P(d_ar), n_slots,
+                      pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv), P(self.w_dump_async), ka, s)
         if n_tiles and fast:
             _lib.call("mm_boot1d_fast", *[P(o) for o in ops], P(d_tile_ptr), n_tiles * 64, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       int(fill_seed) & ((1 << 64) - 1), B, int(mean_only), ld, P(self.ym), P(self.yv), s)
         elif n_tiles:
             _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
-                      pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, s)
+                      pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, n_launch,
+                      ctypes.byref(chain_tiles) if chain_tiles is not None else None, s)
+        if n_launch:
+            torch.cuda.current_stream().wait_stream(side)
         st = int(status.item())
         if st & 2 or st & 4:
             raise RuntimeError(f"mm_bins_order inconsistency (status {st})")

@@ -24,7 +24,11 @@ int main(int argc,char**argv){
     if(p>0.5) p=0.5; if(n>= (1LL<<31)-2) continue; if(p*(double)n<=30.0) continue;
     npyrng::Pcg64 g0{rng(),rng(),rng(),rng()|1};
     npyrng::Pcg64 a=g0,b=g0;
+    #ifdef STRESS_LAZY   // the variant the one-chain-per-wave kernel instantiates (rare-branch set-up kept inside the branches)
+    int32_t yf = npyrng::binomial_btpe_fast<int32_t, true>(a,(int32_t)n,p);
+#else
     int32_t yf = npyrng::binomial_btpe_fast<int32_t>(a,(int32_t)n,p);
+#endif
     int32_t ye = npyrng::binomial_btpe<int32_t>(b,(int32_t)n,p);
     done++;
     if(yf>=0){ fast_ok++; if(yf!=ye || a.s_hi!=b.s_hi || a.s_lo!=b.s_lo){ mism++; if(mism<10) printf("MISMATCH n=%ld p=%.17g fast=%d exact=%d\n",(long)n,p,yf,ye);} }

@@ -83,6 +83,45 @@ void host_multinomial_fast(const uint64_t st[4], int64_t n, const double *pix, i
   delete[] lq;
 }
 
+// the same chain through the RESUMABLE form of the samplers (csrc/npy_rng.h: lane_begin / lane_inv / lane_att / ...), driven the
+// way one lane of the lane-asynchronous tile kernel (csrc/boot.hip: k_boot1d_async) drives it: one phase per pass
+void host_multinomial_async(const uint64_t st[4], int64_t n, const double *pix, int d, int B, int64_t *out) {
+  using namespace npyrng;
+  Pcg64 g{st[0], st[1], st[2], st[3]};
+  double *pk = new double[d], *lq = new double[d];
+  double rem = 1.0;
+  for (int j = 0; j < d - 1; j++) {
+    pk[j] = pix[j] / rem;
+    lq[j] = binomial_lq(pk[j]);
+    rem -= pix[j];
+  }
+  LaneDraw D;
+  for (int b = 0; b < B; b++) {
+    int64_t *mn = out + (int64_t)b * d;
+    int32_t dn = (int32_t)n;
+    int k = 0;
+    int32_t state = LS_START;
+    while (k < d - 1 && dn > 0) {
+      if (state == LS_START) state = lane_begin(D, g, pk[k], lq[k], dn);
+      if (state == LS_INV) state = lane_inv(D);
+      if (state == LS_ATT) state = lane_att(D, g);
+      if (state == LS_EXPL) state = lane_expl(D);
+      if (state == LS_SQZ) state = lane_sqz(D);
+      if (state == LS_XINV) state = lane_xinv(D, g);
+      if (state == LS_XBT) state = lane_xbt(D, g);
+      if (state == LS_DONE) {
+        mn[k] = D.w;
+        dn -= D.w;
+        k++;
+        state = LS_START;
+      }
+    }
+    if (dn > 0) mn[d - 1] = dn;
+  }
+  delete[] pk;
+  delete[] lq;
+}
+
 // count binomial draws through binomial_pre<.., true> with explicit (n, p) and return the two fallback counters
 void host_binomial_fast(const uint64_t st[4], double p, int64_t n, int count, int64_t *out) {
   npyrng::Pcg64 g{st[0], st[1], st[2], st[3]};

@@ -1,0 +1,131 @@
+"""The headline configuration at its own size against the oracle: BASELINE.json configs[2] (1M cells x 20k genes, 3 % nnz, 20
+groups) with **B = 10,000** bootstraps, ``approx=False``, through ``memento.ht_1d_moments`` exactly as ``bench.py`` times it
+(default packing: the long chains one per wave, the rest in tiles, three tile waves per SIMD).
+
+For eight genes -- the one holding the longest chain, the two with the smallest p-values (extreme count <= 10: the
+genextreme tail-fit branch of hypothesis_test.py:57-141), five typical ones -- the oracle (oracle/memento_oracle.py, pinned to
+the real reference by tests/test_oracle_golden.py) is run on the same counts with the same hash uniforms (the global np.random
+stream hands two to every live (gene, group) chain, gene-major: bootstrap.py:62, :65) and must agree: log replicate moments
+1e-11 / 1e-9, coefficients and standard errors 1e-8, p-values 1e-5 (hypothesis_test.py:144-215)."""
+
+import multiprocessing as mp
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_W = {}
+
+
+def _init(shared):
+    sys.path.insert(0, ROOT)
+    _W.update(shared)
+
+
+def _chain(job):
+    """One (gene, group) chain in the oracle: log replicate mean / log replicate residual variance (no fill: C3 has no
+    invalid replicate)."""
+    from oracle import memento_oracle as orc
+
+    col, j, r, r0 = job
+    c = _W
+    mean, var = orc.bootstrap_1d(col.astype(np.float64), c["asf"][j], c["gq"][j], c["num_boot"], r, r0)
+    rv = orc.residual_variance(mean, var, c["fit"])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.log(mean), np.log(rv)
+
+
+def test_c3_headline_config_pvalues_match_the_oracle_at_10000_bootstraps():
+    import torch
+
+    import bench
+    from oracle import memento_oracle as orc
+    from scrna_parameter_estimation_amd import AnnDataLite, engine, memento
+
+    cfg = bench.CONFIGS["C3"]
+    N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
+    assert (N, G, B) == (1_000_000, 20_000, 10_000)
+    ng = cfg["n_cond"] * cfg["n_rep"]
+    csr = bench.synth_device_csr(cfg, 20250117, torch)
+    grp = np.random.default_rng(20250117).integers(0, ng, size=N)
+    obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
+    adata = AnnDataLite(sp.csr_matrix((N, G), dtype=np.float32), obs, pd.DataFrame(index=[f"g{i}" for i in range(G)]))
+    memento.setup_memento(adata, q_column="q", device_csr=csr)
+    memento.create_groups(adata, label_columns=["cond", "rep"])
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == cfg["n_cond"] - 1).astype(float)}, index=gdf.index)
+    memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+    seed = 1000
+    np.random.seed(seed)
+    t0 = time.time()
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=B, num_cpus=16, verbose=0, resampling="bootstrap", approx=False)
+    t_ht = time.time() - t0
+    m = adata.uns["memento"]
+    st = m["_hip"]
+    bs = st.last_bootstrap
+    groups = m["groups"]
+    kept = st.gene_idx
+    assert bs.n_pairs == len(kept) * ng, "one chunk expected at C3 (replicate rows fit in HBM)"
+    assert bs.n_tiles > 2048 and bs.n_chain > 0                 # the bench's packing: both kernels, three tile waves per SIMD
+    assert st.refill_stats["chains_refilled"] == 0              # timed mode == reference-pinned mode at C3 (no invalid replicate)
+    ht = m["1d_ht"]
+    tm = np.stack([m["1d_moments"][g][0] for g in groups])
+    trv = np.stack([m["1d_moments"][g][2] for g in groups])
+    skips = bench.stream_skips(tm, trv)
+    # ---- the eight genes ---------------------------------------------------------------------------------------------
+    Kg = bs.K.reshape(len(kept), ng)
+    g_long = int(np.argmax(Kg.max(axis=1)))
+    pmin = np.minimum(ht["mean_asl"], ht["var_asl"])
+    small = [int(i) for i in np.argsort(pmin)[:2]]
+    assert pmin[small[1]] < 11.5 / (B + 1), "expected two genes beyond the exact-count range (tail-fit branch)"
+    rest = [int(i) for i in np.random.default_rng(5).choice(len(kept), size=12, replace=False) if i not in (g_long, *small)][:5]
+    genes = [g_long] + small + rest
+    cols = bench.sample_columns(csr, kept[genes], torch).astype(np.float32)       # [N][8] dense
+    gid = st.group_id
+    sel = [np.flatnonzero(gid == k) for k in range(ng)]
+    gq = np.array([m["group_q"][g] for g in groups])
+    Nc = np.array([len(s) for s in sel], dtype=np.float64)
+    fit = m["mv_regressor"]["all"]
+    asf = [m["all_approx_size_factor"][s] for s in sel]
+    np.random.seed(seed)
+    u = np.random.random(int(skips[-1]) + 2 * ng)                  # the stream ht_1d_moments consumed
+    # ---- replicate rows, chain by chain, in a process pool (the oracle takes ~0.3 s per chain at B = 10,000) -----------------
+    jobs, where = [], []
+    for a, gi in enumerate(genes):
+        pos = int(skips[gi])
+        for j in range(ng):
+            jobs.append((np.ascontiguousarray(cols[sel[j], a]), j, u[pos], u[pos + 1]))     # every chain is live at C3 (asserted below)
+            where.append((gi, j))
+            pos += 2
+    with np.errstate(invalid="ignore"):
+        assert not (np.isnan(tm[:, genes]) | np.isnan(trv[:, genes]) | (tm[:, genes] == 0) | (trv[:, genes] < 0)).any()
+    shared = dict(asf=asf, gq=gq, num_boot=B, fit=fit)
+    t0 = time.time()
+    with ProcessPoolExecutor(max_workers=16, mp_context=mp.get_context("spawn"), initializer=_init, initargs=(shared,)) as ex:
+        rows = list(ex.map(_chain, jobs, chunksize=2))
+    t_or = time.time() - t0
+    for (gi, j), (lm, lv) in zip(where, rows):
+        p = gi * ng + j
+        np.testing.assert_allclose(engine.host(bs.ym[p, 1:]), lm, rtol=1e-11, atol=1e-13, err_msg=f"gene {gi} group {j} mean")
+        np.testing.assert_allclose(engine.host(bs.yv[p, 1:]), lv, rtol=1e-9, atol=1e-11, err_msg=f"gene {gi} group {j} res var")
+    # ---- regression + ASL on the oracle's rows (hypothesis_test.py:242-300, :57-141) ---------------------------------------
+    nt = trt.shape[1]
+    for a, gi in enumerate(genes):
+        bm = np.full((ng, B + 1), np.nan)
+        bv = np.full((ng, B + 1), np.nan)
+        bm[:, 0], bv[:, 0] = np.log(tm[:, gi]), np.log(trv[:, gi])
+        for j in range(ng):
+            bm[j, 1:], bv[j, 1:] = rows[a * ng + j]
+        want = orc.regress_1d(cov.values, trt.values, bm, bv, Nc, resampling="bootstrap", approx=False)
+        for k, w, tol in zip(("mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"), want, (1e-8, 1e-8, 1e-5) * 2):
+            np.testing.assert_allclose(ht[k][gi * nt:(gi + 1) * nt], np.atleast_1d(w), rtol=tol, atol=1e-12, err_msg=f"gene {gi} {k}")
+    print(f"\nC3 at B=10,000: ht_1d_moments {t_ht:.2f} s for {len(kept)} genes; oracle {len(jobs)} chains in {t_or:.1f} s; "
+          f"genes checked {genes} (K max {int(Kg[g_long].max())}; smallest p {pmin[small[0]]:.2e}, {pmin[small[1]]:.2e})")

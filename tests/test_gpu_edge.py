@@ -84,7 +84,6 @@ def test_replay_weights_edge_and_host_order_fallback(eng, monkeypatch):
         zeros = np.zeros(bs.n_pairs)
         bs.alloc_outputs(zeros, zeros)
         bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
-        wd = eng.host(bs.w_dump)
         rm = eng.host(bs.raw_mean)
         for p in range(bs.n_pairs):
             gene, k = divmod(p, ng)
@@ -94,7 +93,7 @@ def test_replay_weights_edge_and_host_order_fallback(eng, monkeypatch):
                 assert np.isnan(rm[p, 1:]).all()          # bootstrap.py:97-98
                 continue
             w = orc.multinomial_weights(len(sel), mult, B)
-            np.testing.assert_array_equal(wd[bs.pair_slot[p], :len(expr), :], w, err_msg=f"pair {p} caps {caps}")
+            np.testing.assert_array_equal(bs.weights_of(p), w, err_msg=f"pair {p} caps {caps}")
         results.append(rm)
     np.testing.assert_array_equal(results[0], results[1])  # device-ordered and host-ordered operands give identical replicates
 

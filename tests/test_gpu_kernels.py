@@ -169,7 +169,6 @@ def test_replay_bootstrap_bit_exact(eng, orc, api_small):
     zeros = np.zeros(bs.n_pairs)
     bs.alloc_outputs(zeros, zeros)
     bs.run(skip, r1, r0, g["mv_regressor"], fill_mode=1, dump_weights=True)
-    wd = eng.host(bs.w_dump)
     rm, rv = eng.host(bs.raw_mean), eng.host(bs.raw_var)
     Xc = X.tocsc()
     checked = 0
@@ -182,8 +181,7 @@ def test_replay_bootstrap_bit_exact(eng, orc, api_small):
             assert np.isnan(rm[p, 1:]).all()
             continue
         w = orc.multinomial_weights(len(sel), mult, B)
-        slot = bs.pair_slot[p]
-        np.testing.assert_array_equal(wd[slot, :len(expr), :], w)          # integer draws: bit-exact vs numpy
+        np.testing.assert_array_equal(bs.weights_of(p), w)                 # integer draws: bit-exact vs numpy
         m, v = orc.replicate_moments_1d(expr, inv_sf, inv_sf_sq, w, len(sel), g["group_q"][k])
         # numpy sums the K bins pairwise (the weights are a transposed view, so the bin axis is contiguous);
         # the kernel accumulates sequentially in fp64: equal to ~1 ulp, far inside the 1e-5 bar.

@@ -127,12 +127,19 @@ def test_histograms_and_multinomial_invariants(big):
     zeros = np.zeros(bs.n_pairs)
     bs.alloc_outputs(zeros, zeros)
     bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
-    w = bs.w_dump                                                          # [slot][k][B] int32 on device
-    tot = w.sum(dim=1).cpu().numpy()                                       # multinomial weights of every replicate sum to N_g
-    act = np.flatnonzero(bs.slot_pair >= 0)
-    want = Nc[bs.slot_pair[act] % ng]
-    assert (tot[act] == want[:, None]).all()
-    assert (w >= 0).all().item()
+    # multinomial weights of every replicate sum to N_g and are non-negative, whichever kernel drew them
+    n_seen = 0
+    if bs.n_tiles:                                                         # lock-step tiles: [slot][k][B] int32 on device
+        w = bs.w_dump
+        act = np.flatnonzero(bs.slot_pair >= 0)
+        assert (w.sum(dim=1).cpu().numpy()[act] == Nc[bs.slot_pair[act] % ng][:, None]).all() and (w >= 0).all().item()
+        n_seen += len(act)
+    for wd, pairs, rows in ((bs.w_dump_chain, bs.chain_pairs, None), (bs.w_dump_async, bs.async_pairs, getattr(bs, "async_slot", None))):
+        if len(pairs):                                                     # one chain per wave / lane-asynchronous tiles
+            tot = wd.sum(dim=1).cpu().numpy()
+            assert (tot[rows if rows is not None else slice(None)] == Nc[pairs % ng][:, None]).all() and (wd >= 0).all().item()
+            n_seen += len(pairs)
+    assert n_seen == int(bs.active.sum()) and bs.n_async > 0
     # replicate means are non-negative and finite; bootstrap mean of the replicate means is close to the estimate
     rm = engine.host(bs.raw_mean)[:, 1:]
     assert np.isfinite(rm[bs.active]).all() and (rm[bs.active] >= 0).all()
@@ -164,9 +171,47 @@ def test_replay_is_independent_of_the_packing(big, monkeypatch):
     np.testing.assert_array_equal(out[0][2], out[1][2])
 
 
-def test_replay_weights_bit_exact_at_scale(big):
+def test_three_replay_kernels_agree_bit_for_bit(big, monkeypatch):
+    """The same chains through (a) the lane-asynchronous tile kernel (mm_boot1d_async: every lane at its own pace, the draw as a
+    resumable state machine), (b) the one-wave-per-chain kernel (mm_boot1d_chain: wave-uniform samplers fed by lane-parallel PCG64
+    batches) and (c) the lock-step tile kernel of rounds 1-2 (mm_boot1d_replay): integer weights and replicate moments
+    bit-identical."""
+    engine, torch, csr, gid, blocks, sf = big
+    S, sumx, maxx = blocks.moments(1.0 / sf)
+    rng = np.random.default_rng(33)
+    ng = blocks.n_groups
+    genes = np.sort(rng.choice(np.flatnonzero(sumx.sum(axis=0) > 3000), size=40, replace=False))
+    n_bins = 31
+    sf_bin = rng.integers(0, n_bins, size=csr.shape[0]).astype(np.uint8)
+    sf_table = np.linspace(0.4, 2.5, n_bins)
+    B = 150           # > 128: several 64-replicate output groups of the chain kernel and a ragged last one
+    out = []
+    for mode, min_k in (("async", 0), ("lockstep", 2), ("lockstep", 0)):
+        monkeypatch.setattr(engine, "TILE_MODE", mode)
+        monkeypatch.setattr(engine, "ASYNC_CHAIN_MIN_K", 0)
+        monkeypatch.setattr(engine, "CHAIN_MIN_K", min_k)
+        monkeypatch.setattr(engine, "CHAIN_LONE", False)
+        bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(ng, 0.07), B)
+        r = np.random.default_rng(4).random((2, bs.n_pairs))
+        zeros = np.zeros(bs.n_pairs)
+        bs.alloc_outputs(zeros, zeros)
+        bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
+        n_act = int(bs.active.sum())
+        assert (bs.n_async, bs.n_chain, bs.n_tiles > 0) == {("async", 0): (n_act, 0, False), ("lockstep", 2): (0, n_act, False),
+                                                            ("lockstep", 0): (0, 0, True)}[(mode, min_k)]
+        out.append((engine.host(bs.raw_mean), engine.host(bs.raw_var), [bs.weights_of(p) for p in range(0, bs.n_pairs, 9)]))
+    for other in out[1:]:
+        np.testing.assert_array_equal(out[0][0], other[0])
+        np.testing.assert_array_equal(out[0][1], other[1])
+        for a, b in zip(out[0][2], other[2]):
+            np.testing.assert_array_equal(a, b)
+    assert np.isfinite(out[0][0][:, 1:]).any()
+
+
+def test_replay_weights_bit_exact_at_scale(big, monkeypatch):
     """BTPE-heavy stress of the samplers on the device: >1e6 draws on 12k-cell (C2) / 48k-cell (C3) groups must equal
-    numpy's Generator(PCG64(5)).multinomial draw for draw."""
+    numpy's Generator(PCG64(5)).multinomial draw for draw -- the longer half of the chains through the one-wave-per-chain
+    kernel, the shorter half through the lane-asynchronous tile kernel."""
     engine, torch, csr, gid, blocks, sf = big
     S, sumx, maxx = blocks.moments(1.0 / sf)
     rng = np.random.default_rng(3)
@@ -181,16 +226,17 @@ def test_replay_weights_bit_exact_at_scale(big):
     r = rng.random((2, bs.n_pairs))
     zeros = np.zeros(bs.n_pairs)
     bs.alloc_outputs(zeros, zeros)
+    monkeypatch.setattr(engine, "CHAIN_MIN_K", int(np.median(bs.K[bs.K >= 2])) + 1)
     bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
-    wd = engine.host(bs.w_dump)
     n_draws = 0
+    assert bs.n_chain > 0 and bs.n_async > 0                               # both kernels are exercised
     for p in range(bs.n_pairs):
         bi, xi, mu = bs.bins_of_pair(p)
         code = xi.astype(np.float64) * r[0][p] + r[1][p] * sf_table[bi]
         o = np.argsort(code, kind="stable")
         mult = mu[o].astype(np.int64)
         want = np.random.Generator(np.random.PCG64(5)).multinomial(int(blocks.grp_ncells[p % ng]), mult / mult.sum(), size=B).T
-        np.testing.assert_array_equal(wd[bs.pair_slot[p], :len(mult), :], want, err_msg=f"pair {p}")
+        np.testing.assert_array_equal(bs.weights_of(p), want, err_msg=f"pair {p}")
         n_draws += (len(mult) - 1) * B
     assert n_draws > 1_000_000
 

@@ -84,7 +84,7 @@ def test_multinomial_random_shapes(shim):
         pv = mult / mult.sum()
         B = 50
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
-        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async"):
             got = _multi(shim, 5, n, pv, B, fn)
             np.testing.assert_array_equal(got, ref, err_msg=f"{fn} trial {trial} d={d} n={n}")
 
@@ -93,7 +93,7 @@ def test_multinomial_golden_weights(shim, internals_small):
     it = internals_small
     for k in range(int(it["n_picks"])):
         mult = it[f"p{k}_counts"]
-        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async"):
             got = _multi(shim, 5, int(it[f"p{k}_n_obs"]), mult / mult.sum(), int(it["num_boot"]), fn)
             np.testing.assert_array_equal(got.T, it[f"p{k}_weights"])
 
@@ -117,6 +117,32 @@ def test_guarded_fast_binomial_matches_numpy(shim, n, p):
     np.testing.assert_array_equal(out, ref)
     inv_fb, f_fb = _fallbacks(shim)
     assert inv_fb + f_fb < 0.02 * cnt + 5, (inv_fb, f_fb)          # the fast path really is the common path
+
+
+@pytest.mark.parametrize("which", ["plain", "perturbed"])
+def test_resumable_samplers_multinomial_stress(shim, shim_perturbed, which):
+    """The phase-wise (resumable) form of the samplers that the lane-asynchronous tile kernel runs: C3-like chains and chains
+    with long inversion searches (n p up to 30: the search continues over several passes), > 2.5e6 draws, every weight numpy's;
+    also with the cheap primitives perturbed."""
+    lib = shim if which == "plain" else shim_perturbed
+    rng = np.random.default_rng(21)
+    draws = 0
+    _fallbacks(lib)
+    for trial in range(40):
+        d = int(rng.integers(40, 350))
+        heavy = max(3, d // 3)
+        mult = np.concatenate([rng.integers(200, 9000, size=heavy // 3 + 1), rng.integers(5, 60, size=heavy),
+                               rng.integers(1, 20, size=d - heavy - heavy // 3 - 1)])
+        rng.shuffle(mult)
+        n = int(mult.sum())
+        pv = mult / mult.sum()
+        B = 400
+        ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
+        got = _multi(lib, 5, n, pv, B, "host_multinomial_async")
+        np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial} d={d} n={n}")
+        draws += (d - 1) * B
+    inv_fb, f_fb = _fallbacks(lib)
+    assert draws > 2_500_000 and inv_fb < 1e-2 * draws and f_fb < 5e-3 * draws, (draws, inv_fb, f_fb)
 
 
 def test_guarded_fast_multinomial_stress(shim):
@@ -144,16 +170,18 @@ def test_guarded_fast_multinomial_stress(shim):
     assert inv_fb < 5e-3 * draws and f_fb < 5e-3 * draws
 
 
-@pytest.mark.parametrize("perturb", [False, True])
-def test_guarded_fast_btpe_never_disagrees_with_exact_btpe(tmp_path, perturb):
+@pytest.mark.parametrize("perturb,lazy", [(False, False), (True, False), (True, True)])
+def test_guarded_fast_btpe_never_disagrees_with_exact_btpe(tmp_path, perturb, lazy):
     """binomial_btpe_fast (fp64 set-up through fast reciprocals, fp32 logarithms / explicit product / Stirling bound, every decision
     guarded) vs the exact BTPE on ~6e6 random (n, p, state) over n in [60, 2^31), p in (0, 0.5]: whenever the fast path returns a
     draw, the draw and the generator state after it are identical; it decides > 99 % of the draws.  With ``perturb`` every cheap
-    primitive carries 2-4x the error of the hardware instruction it maps to on the GPU."""
+    primitive carries 2-4x the error of the hardware instruction it maps to on the GPU; ``lazy`` = the instantiation of the
+    one-chain-per-wave kernel (set-up of the rarer branches computed inside them)."""
     exe = tmp_path / "btpe_stress"
     src = os.path.join(ROOT, "tests", "host_shim", "btpe_stress.cpp")
     inc = os.path.join(ROOT, "scrna_parameter_estimation_amd", "csrc")
-    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", inc] + (["-DNPY_HOST_PERTURB"] if perturb else []) + [src, "-o", str(exe)])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", inc] + (["-DNPY_HOST_PERTURB"] if perturb else []) +
+                          (["-DSTRESS_LAZY"] if lazy else []) + [src, "-o", str(exe)])
     r = subprocess.run([str(exe), "6000000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     words = r.stdout.split()

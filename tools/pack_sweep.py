@@ -1,6 +1,6 @@
 """Sweep of the replay kernel's lane-packing constants (engine.PACK_C0 / PACK_C1 / PACK_WAVES) on one shape, in ONE process.
 These are module attributes the tools set directly; the product path reads no environment variable.
-usage: python tools/pack_sweep.py [config=C3 | C3@cells[@num_boot]] "c0,c1,waves[,max_resident[,pair_slots]]" ..."""
+usage: python tools/pack_sweep.py [config=C3 | C3@cells[@num_boot]] "c0,c1,waves[,max_resident[,pair_slots[,waves3]]]" ..."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch, scipy.sparse as sp
@@ -35,8 +35,9 @@ for combo in combos:
     engine.PACK_C0, engine.PACK_C1, engine.PACK_WAVES = float(c0), float(c1), int(waves)
     engine.PACK_MAX_RESIDENT = int(combo[3]) if len(combo) > 3 else 2048
     engine.PAIR_SLOTS = int(combo[4]) if len(combo) > 4 else 1024
+    engine.PACK_WAVES3 = int(combo[5]) if len(combo) > 5 else 2750
     _lib.call("mm_timer_begin", timer, s)
     bs.run(skip, r[0], r[1], m["mv_regressor"]["all"], fill_mode=1)
     _lib.call("mm_timer_end", timer, s)
     _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(ms))
-    print(f"{name} C0={c0:g} C1={c1:g} waves={int(waves)} -> tiles {bs.n_tiles} ({engine.PACK_LAST.get('chosen')})  bootstrap {ms.value:.0f} ms; model: longest tile {engine.PACK_LAST.get('longest_resident', 0) * B * 1e-6:.2f} s, work / rate {engine.PACK_LAST.get('work_resident', 0) * B * 1e-6:.2f} s, chains {engine.PACK_LAST.get('chains')}, K max {int(bs.K.max())} mean {bs.K[bs.K >= 2].mean():.0f}", flush=True)
+    print(f"{name} C0={c0:g} C1={c1:g} waves={int(waves)} waves3={engine.PACK_WAVES3} -> tiles {bs.n_tiles} of them chain waves {bs.n_chain} ({engine.PACK_LAST.get('chosen')})  bootstrap {ms.value:.0f} ms; model: longest tile {engine.PACK_LAST.get('longest_resident', 0) * B * 1e-6:.2f} s, work / rate {engine.PACK_LAST.get('work_resident', 0) * B * 1e-6:.2f} s, chains {engine.PACK_LAST.get('chains')}, K max {int(bs.K.max())} mean {bs.K[bs.K >= 2].mean():.0f}", flush=True)

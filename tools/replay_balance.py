@@ -32,7 +32,7 @@ def main():
         skip = ~(np.isfinite(np.log(tm)) & np.isfinite(np.log(tv)))
         bs.alloc_outputs(np.log(tm), np.log(tv))
     r = np.random.default_rng(0).random((2, bs.n_pairs))
-    buf = torch.zeros((1 << 16) * 4, dtype=torch.int64, device="cuda")
+    buf = torch.zeros((1 << 20,), dtype=torch.int64, device="cuda")   # tiles at 0, the chain kernel at engine.CHAIN_CLOCK_OFF
     _lib.call("mm_debug_wave_clock", engine.P(buf))
     torch.cuda.synchronize(); t0 = time.time()
     bs.run(skip, r[0], r[1], m["mv_regressor"]["all"])
