@@ -49,11 +49,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 TRAFFIC_FILE = "r02_k1_traffic_C3.json"   # this round's PMC record of K1's HBM traffic (tools/k1_traffic.py)
 
 
-def synth_device_csr(cfg, seed, torch, gene_lo=0, gene_hi=None):
-    """Gamma-Poisson counts generated ON THE GPU (SURVEY.md section 8d shape); returns engine.DeviceCSR.
-    ``gene_lo/gene_hi``: only that gene range of the matrix (strong scaling: every rank calibrates the SAME 20k-gene
-    expression profile and generates its own columns)."""
-    from scrna_parameter_estimation_amd import engine
+def calibrated_profile(cfg, seed):
+    """Per-gene base means mu (all G genes) rescaled so that the expected nnz fraction hits cfg['density'], and the cell depths
+    (SURVEY.md section 8d).  Host only; every rank computes the same arrays."""
     from scrna_parameter_estimation_amd.synth import _expected_density
 
     N, G, dens = cfg["cells"], cfg["genes"], cfg["density"]
@@ -69,11 +67,22 @@ def synth_device_csr(cfg, seed, torch, gene_lo=0, gene_hi=None):
             lo = mid
         else:
             hi = mid
-    mu = mu * np.sqrt(lo * hi)
-    if gene_hi is not None:
-        mu = mu[gene_lo:gene_hi]
+    return mu * np.sqrt(lo * hi), depth
+
+
+def synth_device_csr(cfg, seed, torch, genes=None):
+    """Gamma-Poisson counts generated ON THE GPU (SURVEY.md section 8d shape); returns engine.DeviceCSR.
+    ``genes``: only those genes of the matrix (ascending indices; strong scaling: every rank calibrates the SAME 20k-gene
+    expression profile and generates the columns of its own shard)."""
+    from scrna_parameter_estimation_amd import engine
+
+    N, G = cfg["cells"], cfg["genes"]
+    mu, depth = calibrated_profile(cfg, seed)
+    if genes is not None:
+        genes = np.asarray(genes, dtype=np.int64)
+        mu = mu[genes]
         G = len(mu)
-        seed = seed + 7919 * (gene_lo + 1)
+        seed = seed + 7919 * (int(genes[0]) + 1 if len(genes) else 1)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
     d_mu = torch.from_numpy(mu.astype(np.float32)).cuda()
@@ -97,6 +106,14 @@ def synth_device_csr(cfg, seed, torch, gene_lo=0, gene_hi=None):
     indptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
     indptr[1:] = torch.cumsum(counts, 0)
     return engine.DeviceCSR.from_device(indptr, torch.cat(idx_parts), torch.cat(val_parts).to(torch.float32), (N, G))
+
+
+def balanced_shard(cfg, rank, world, seed=20250117):
+    """Gene indices of rank ``rank``'s cost-balanced shard of the synthetic matrix (every rank computes the same partition)."""
+    from scrna_parameter_estimation_amd.dist import gene_cost, shard_genes_balanced
+
+    mu, _ = calibrated_profile(cfg, seed)
+    return shard_genes_balanced(gene_cost(mu * float(np.exp(0.35 ** 2 / 2))), rank, world)     # E[depth] = exp(sigma^2 / 2), E[gamma] = 1
 
 
 def sample_columns(csr, genes, torch):
@@ -123,6 +140,14 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-baseline-cores", type=int, default=max(1, min(16, os.cpu_count() or 1)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--predict-shards", type=int, default=0, metavar="N",
+                    help="single process, no collectives: time the step of each of the N cost-balanced gene shards of the config on this "
+                         "GPU, one after the other, and print the per-shard times and the predicted N-GPU makespan (a PREDICTION, "
+                         "not a multi-GPU measurement)")
+    ap.add_argument("--extra", action="store_true",
+                    help="also time BASELINE.json configs[3] (one GPU's share: 250 x 2000 gene pairs, 500k cells, 1k bootstraps) and "
+                         "configs[4] (Perturb-seq: 200k x 15k, 500 guides vs control, 5k bootstraps) and add pair_tests_per_s / "
+                         "vs_control_tests_per_s to the JSON line (N = 1 only; about two more minutes)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: the same 20k-gene matrix split over the ranks (configs[2]); weak: a full-size gene shard per rank")
     args = ap.parse_args()
@@ -158,16 +183,20 @@ def main():
     _lib.load(require_gpu=True)
     N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
     n_groups = cfg["n_cond"] * cfg["n_rep"]
+    if args.predict_shards:
+        return predict_shards(args, cfg, torch)
 
     # ---- untimed preparation: data in HBM, size factors, groups + count blocks -------------------
     t0 = time.time()
     G_total = G
+    mine = None
     if args.scaling == "strong" and world > 1:
-        from scrna_parameter_estimation_amd.dist import shard_genes
-        g_lo, g_hi = shard_genes(G_total, rank, world)
-        csr = synth_device_csr(cfg, 20250117, torch, g_lo, g_hi)     # the same matrix on any world size: this rank's gene range
-        G = g_hi - g_lo
-        var = pd.DataFrame(index=[f"g{i}" for i in range(g_lo, g_hi)])
+        # the same matrix on any world size: this rank generates the columns of ITS cost-balanced gene shard (dist.py: LPT over
+        # the predicted chain cost of every gene, here from the calibrated expression profile every rank can compute)
+        mine = balanced_shard(cfg, rank, world)
+        csr = synth_device_csr(cfg, 20250117, torch, genes=mine)
+        G = len(mine)
+        var = pd.DataFrame(index=[f"g{i}" for i in mine])
     else:
         csr = synth_device_csr(cfg, 20250117 + 1000 * rank, torch)  # weak: every rank its own full-size gene shard (same cells)
         var = pd.DataFrame(index=[f"r{rank}g{i}" for i in range(G)])
@@ -176,7 +205,7 @@ def main():
     obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
     Xstub = sp.csr_matrix((N, G), dtype=np.float32)                   # shape only: the counts live in HBM
     adata = AnnDataLite(Xstub, obs, var)
-    memento.setup_memento(adata, q_column="q", device_csr=csr, comm=comm)
+    memento.setup_memento(adata, q_column="q", device_csr=csr, comm=comm, shard=mine if mine is not None else False)
     memento.create_groups(adata, label_columns=["cond", "rep"])
     gdf = memento.get_groups(adata)
     cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
@@ -287,9 +316,15 @@ def main():
         _lib.call("mm_timer_end", timer, stream)
         _lib.call("mm_timer_elapsed_ms", timer, ctypes.byref(ms))
         draws = bs.draws_per_replicate * B
-        boot = {"kernel": "k_boot1d_replay(+order,fill)", "binomial_draws": int(draws), "ms": round(ms.value, 2),
-                "draws_per_s": round(draws / (ms.value * 1e-3), 1), "pairs": int((~skip).sum()), "waves": int(bs.n_tiles), "wave_steps_per_replicate": int(bs.tile_ptr[-1]), "K_max": int(bs.K.max()), "K_mean": round(float(bs.K[~skip].mean()), 1),
-                "rng": "numpy-PCG64-replay"}
+        chain_steps = int(np.maximum(bs.K[bs.chain_pairs] - 1, 0).sum()) if bs.n_chain else 0      # chains that run one per wave
+        wave_steps = int(bs.tile_ptr[-1]) + chain_steps
+        boot = {"kernel": "k_boot1d_replay (lane-per-chain tiles; chains alone in their tile run wave-uniform: chain_body) + order, fill",
+                "binomial_draws": int(draws), "ms": round(ms.value, 2),
+                "draws_per_s": round(draws / (ms.value * 1e-3), 1), "pairs": int((~skip).sum()), "waves": int(bs.n_tiles),
+                "chain_waves": int(bs.n_chain), "wave_steps_per_replicate": wave_steps,
+                "lane_occupancy": round(bs.draws_per_replicate / max(1, wave_steps * 64), 4),
+                "lane_occupancy_is": "useful draws / (wave-steps x 64); a chain wave counts one useful lane per step",
+                "K_max": int(bs.K.max()), "K_mean": round(float(bs.K[~skip].mean()), 1), "rng": "numpy-PCG64-replay"}
         rs = getattr(state, "refill_stats", None)
         if rs and rs["chains"]:
             # timed mode = strict=False: invalid replicates refilled on the device; every chain WITHOUT a refill is bit-identical
@@ -308,22 +343,186 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, cfg, adata, csr, state, cov, trt, torch, last_seed=1000 + args.steps - 1)
 
+    e2e = None
+    if rank == 0 and world == 1:
+        # SURVEY 8(d)'s metric to the letter: the step PLUS the upload of the CSR from pinned host memory and create_groups (K0
+        # ingest) once per step -- value stays "inputs resident in HBM", value_e2e is printed beside it
+        import ctypes
+
+        c = state.csr
+        host_parts = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t) for t in (c.indptr, c.indices, c.data)]
+        torch.cuda.synchronize()
+        t0 = time.time()
+        up = [h.to("cuda", non_blocking=True) for h in host_parts]
+        torch.cuda.synchronize()
+        h2d_s = time.time() - t0
+        del up, host_parts
+        k0 = {}
+        t0 = time.time()
+        tmp = engine.CountBlocks(state.csr, state.group_id, n_groups, timing=k0)
+        torch.cuda.synchronize()
+        ingest_s = time.time() - t0
+        del tmp
+        step_s = elapsed / args.steps
+        e2e = {"value_e2e": round((n_tests / args.steps) / (step_s + h2d_s + ingest_s), 2), "h2d_ms": round(1000 * h2d_s, 1),
+               "ingest_ms": round(1000 * ingest_s, 1), "ingest_kernels_ms": round(sum(k0.values()), 2),
+               "csr_bytes": int(c.nbytes), "h2d_GBps": round(c.nbytes / h2d_s / 1e9, 1),
+               "what": "gene-tests / (step + pinned-host -> HBM upload of the CSR + create_groups' ingest), per step; results reach the host inside the step"}
     if rank == 0:
         value = n_tests / elapsed
+        metric = ("gene-tests/sec (1D moments + 10k bootstraps), 1M\u00d720k sparse, 1/2/4/8 GPU" if args.config == "C3"
+                  else "gene-tests/sec (1D moments + bootstrap hypothesis test)")
         line = {
-            "metric": "gene-tests/sec (1D moments + bootstrap hypothesis test)", "value": round(value, 2), "unit": "gene-tests/s",
+            "metric": metric, "value": round(value, 2), "unit": "gene-tests/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {N} cells x {G_total if args.scaling == 'strong' else G} genes"
                                    f"{' in total' if args.scaling == 'strong' else '/GPU'}, {cfg['density']:.0%} nnz, {n_groups} groups, "
                                    f"{B} bootstraps, 1D moments + ht (resampling=bootstrap, approx=False)",
-                       "rng": "numpy PCG64 multinomial replay; device refill of invalid replicates", "parallelism": f"genes x{world}",
+                       "rng": "numpy PCG64 multinomial replay; device refill of invalid replicates", "parallelism": f"genes x{world} (cost-balanced shards)" if world > 1 else "1 GPU",
                        "host_tail_fit_procs": args.num_cpus, "prep_s": round(prep_s, 2)},
             "roofline": roof, "roofline_csr": roof_csr, "bootstrap": boot, "cpu_baseline": cpu, "reference_cpu": reference_cpu(args.config),
+            "e2e": e2e,
         }
+        if e2e:
+            line["value_e2e"] = e2e["value_e2e"]
+        if args.extra and world == 1:
+            state.last_bootstrap = None
+            del csr, adata, state
+            torch.cuda.empty_cache()
+            line.update(extra_configs(torch))
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def extra_configs(torch):
+    """--extra: the other two GPU configurations of BASELINE.json on one GPU, as tools/bench_2d.py / tools/bench_vs_control.py run
+    them (tests/test_gpu_configs.py holds their parity checks): configs[3]'s per-GPU share of the 2000 x 2000 pair grid and the
+    whole of configs[4]."""
+    import scipy.sparse as sp
+
+    from scrna_parameter_estimation_amd import AnnDataLite, memento
+
+    out = {}
+    # configs[3]: 250 x 2000 = 500,000 pairs (one of eight GPUs' share), 500k cells, 2 groups, 1,000 bootstraps
+    cells, genes, B = 500_000, 8_000, 1_000
+    csr = synth_device_csr(dict(cells=cells, genes=genes, density=0.08), 3, torch)
+    grp = np.random.default_rng(1).integers(0, 2, size=cells)
+    adata = AnnDataLite(sp.csr_matrix((cells, genes), dtype=np.float32), pd.DataFrame({"cond": grp, "q": np.full(cells, 0.07)}),
+                        pd.DataFrame(index=[f"g{i}" for i in range(genes)]))
+    memento.setup_memento(adata, q_column="q", device_csr=csr)
+    memento.create_groups(adata, label_columns=["cond"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+    names = memento.main._var_names(adata)
+    pairs = [(a, b) for a in names[:250] for b in names[250:2250]]
+    gdf = memento.get_groups(adata)
+    cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+    trt = pd.DataFrame({"cond": gdf["cond"].astype(float)}, index=gdf.index)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    memento.compute_2d_moments(adata, pairs)
+    np.random.seed(12)
+    memento.ht_2d_moments(adata, covariate=cov, treatment=trt, num_boot=B, num_cpus=8, verbose=0, resampling="bootstrap", approx=True)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    out["pair_tests_per_s"] = round(len(pairs) / dt, 1)
+    out["pair_tests_config"] = f"configs[3], one GPU's share: {len(pairs)} pairs, {cells} cells, 2 groups, {B} bootstraps, {dt:.1f} s"
+    adata.uns["memento"]["_hip"].last_bootstrap2d = None
+    del adata, csr
+    torch.cuda.empty_cache()
+    # configs[4]: 200k cells x 15k genes, 500 guides + control (20 % of the cells), 5,000 bootstraps, one batched call
+    cells, genes, n_guides, B = 200_000, 15_000, 500, 5_000
+    csr = synth_device_csr(dict(cells=cells, genes=genes, density=0.05), 20250117 + 5, torch)
+    rng = np.random.default_rng(20250117 + 5)
+    is_ctrl = rng.random(cells) < 0.2
+    guide = np.where(is_ctrl, 0, 1 + rng.integers(0, n_guides, size=cells))
+    adata = AnnDataLite(sp.csr_matrix((cells, genes), dtype=np.float32), pd.DataFrame({"guide": guide, "q": np.full(cells, 0.07)}),
+                        pd.DataFrame(index=[f"g{i}" for i in range(genes)]))
+    memento.setup_memento(adata, q_column="q", device_csr=csr)
+    memento.create_groups(adata, label_columns=["guide"])
+    memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+    ctrl = [g for g in adata.uns["memento"]["groups"] if g.split("^")[-1] == "0"][0]
+    np.random.seed(0)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    df = memento.ht_1d_vs_control(adata, control=ctrl, num_boot=B, num_cpus=16, approx=True)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    out["vs_control_tests_per_s"] = round(len(df) / dt, 1)
+    out["vs_control_config"] = f"configs[4]: {len(df)} (gene, guide) tests, {cells} cells x {genes} genes, {n_guides} guides + control, {B} bootstraps, {dt:.1f} s"
+    return out
+
+
+def predict_shards(args, cfg, torch):
+    """--predict-shards N: the step of each of the N cost-balanced gene shards, timed alone on this GPU (single process, no
+    collectives; the shard runs with the size factors of the whole matrix, its own pooled mean-variance fit).  The N-GPU strong-
+    scaling run does this concurrently, so its step takes about the longest shard's time plus the small exchanges: a PREDICTION
+    of the makespan, printed as such -- not a multi-GPU measurement."""
+    import scipy.sparse as sp
+
+    from scrna_parameter_estimation_amd import AnnDataLite, memento
+
+    n = args.predict_shards
+    N, G, B = cfg["cells"], cfg["genes"], cfg["num_boot"]
+    n_groups = cfg["n_cond"] * cfg["n_rep"]
+    csr = synth_device_csr(cfg, 20250117, torch)
+    grp = np.random.default_rng(20250117).integers(0, n_groups, size=N)
+    obs = pd.DataFrame({"cond": grp // cfg["n_rep"], "rep": grp % cfg["n_rep"], "q": np.full(N, 0.07)})
+    full = AnnDataLite(sp.csr_matrix((N, G), dtype=np.float32), obs.copy(), pd.DataFrame(index=[f"g{i}" for i in range(G)]))
+    memento.setup_memento(full, q_column="q", device_csr=csr)
+    sf = full.obs["memento_size_factor"].values.copy()
+    shards = []
+    for r in range(n):
+        mine = balanced_shard(cfg, r, n)
+        sub = csr.colselect(mine)
+        adata = AnnDataLite(sp.csr_matrix((N, len(mine)), dtype=np.float32), obs.copy(), pd.DataFrame(index=[f"g{i}" for i in mine]))
+        memento.setup_memento(adata, q_column="q", device_csr=sub, size_factor=sf)
+        memento.create_groups(adata, label_columns=["cond", "rep"])
+        gdf = memento.get_groups(adata)
+        cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+        trt = pd.DataFrame({"cond": (gdf["cond"].astype(int) == cfg["n_cond"] - 1).astype(float)}, index=gdf.index)
+        state = adata.uns["memento"]["_hip"]
+        full_idx = state.gene_idx.copy()
+
+        def step(seed):
+            state.gene_idx = full_idx.copy()
+            state.var_names = None
+            for k in ("size_factor", "approx_size_factor", "all_approx_size_factor"):
+                adata.uns["memento"].pop(k, None)
+            for g in adata.uns["memento"]["groups"]:
+                adata.uns["memento"]["group_cells"][g].shape = (adata.uns["memento"]["group_cells"][g].shape[0], len(mine))
+            np.random.seed(seed)
+            memento.compute_1d_moments(adata, min_perc_group=0.7, subset_var=False)
+            memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=B, num_cpus=args.num_cpus, verbose=0,
+                                  resampling="bootstrap", approx=False)
+            return len(state.gene_idx) * trt.shape[1]
+
+        for w in range(args.warmup):
+            step(100 + w)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        tests = 0
+        for k in range(args.steps):
+            tests += step(1000 + k)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / args.steps
+        bs = state.last_bootstrap
+        shards.append({"rank": r, "genes": int(len(mine)), "tests_per_step": int(tests // args.steps), "ms_per_step": round(1000 * dt, 1),
+                       "chains": int((bs.K >= 2).sum()), "K_max": int(bs.K.max()), "chain_waves": int(bs.n_chain), "tile_waves": int(bs.n_tiles),
+                       "draws_per_replicate": int(bs.draws_per_replicate)})
+        print(json.dumps({"shard": shards[-1]}), file=sys.stderr, flush=True)
+        state.last_bootstrap = None
+        del adata, sub, state, bs
+        torch.cuda.empty_cache()
+    makespan = max(s_["ms_per_step"] for s_ in shards)
+    total = sum(s_["tests_per_step"] for s_ in shards)
+    print(json.dumps({"metric": "PREDICTED strong-scaling makespan from per-shard step times on ONE GPU (not a multi-GPU measurement)",
+                      "config": args.config, "n_shards": n, "sharding": "dist.shard_genes_balanced (LPT over predicted chain cost)",
+                      "shards": shards, "predicted_ms_per_step": makespan, "predicted_value": round(total / (makespan * 1e-3), 2),
+                      "unit": "gene-tests/s", "steps": args.steps, "warmup": args.warmup,
+                      "note": "each shard alone on the GPU, whole-matrix size factors, no collectives; the N-rank run adds one "
+                              "all-gather of the pooled-fit inputs and the result gather per step"}), flush=True)
 
 
 def reference_cpu(config):

@@ -73,6 +73,15 @@ int mm_csr_colcount(const int64_t *d_indptr, const int32_t *d_indices, int64_t n
 int mm_csr_colsplit(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows, int32_t col_lo,
                     int32_t col_hi, const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_data, void *stream);
 
+/* The same for an arbitrary gene SET (cost-balanced shards are not contiguous): d_col_map[g] = new id of a kept gene, -1 = dropped;
+ * the new ids must ascend with g so that rows stay sorted.  mm_csr_colsum: per-gene totals (the cost the balancing uses). */
+int mm_csr_mapcount(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, const int32_t *d_col_map, int64_t *d_row_nnz,
+                    void *stream);
+int mm_csr_mapsplit(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows, const int32_t *d_col_map,
+                    const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_data, void *stream);
+int mm_csr_colsum(const int32_t *d_indices, const float *d_data, int64_t nnz, double *d_out /* [n_genes], zeroed by the caller */,
+                  void *stream);
+
 /* ---- K0: ingest = CSR -> group-ordered SELL count blocks --------------------------------------
  * replaces util._select_cells(adata, group) = adata.X[mask].tocsc() per group
  *   memento/util.py:8-13, memento/main.py:128

@@ -48,6 +48,9 @@ _SIGS = {
     "mm_csr_rowsum": ([c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_csr_colcount": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "mm_csr_colsplit": ([c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_csr_mapcount": ([c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_csr_mapsplit": ([c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "mm_csr_colsum": ([c_void_p, c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "mm_sell_count": ([c_void_p] * 5 + [c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_sell_layout": ([c_void_p, c_int32, c_int32] + [c_void_p] * 8, ctypes.c_int),
     "mm_sell_scatter": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 5, ctypes.c_int),

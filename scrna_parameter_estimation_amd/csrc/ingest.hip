@@ -72,6 +72,55 @@ __global__ __launch_bounds__(256) void k_csr_colsplit(const int64_t *__restrict_
   }
 }
 
+// Cost-balanced gene shards are NOT contiguous ranges: the same two passes with a column map (new id of a kept column, -1 =
+// dropped; ascending in the old id, so rows stay sorted), and the per-gene totals the balancing is computed from.
+__global__ __launch_bounds__(256) void k_csr_mapcount(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      int64_t n_rows, const int32_t *__restrict__ col_map, int64_t *__restrict__ row_nnz) {
+  int lane = mm_lane();
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n_rows; r += nwaves) {
+    int64_t s = indptr[r], e = indptr[r + 1];
+    int cnt = 0;
+    for (int64_t i = s + lane; i < e; i += 64) cnt += col_map[indices[i]] >= 0 ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) row_nnz[r] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_csr_mapsplit(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      const float *__restrict__ data, int64_t n_rows, const int32_t *__restrict__ col_map,
+                                                      const int64_t *__restrict__ out_indptr, int32_t *__restrict__ out_indices,
+                                                      float *__restrict__ out_data) {
+  int lane = mm_lane();
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n_rows; r += nwaves) {
+    int64_t s = indptr[r], e = indptr[r + 1];
+    int64_t o = out_indptr[r];
+    for (int64_t i0 = s; i0 < e; i0 += 64) {   // wave-uniform trip count: every lane reaches the ballot
+      int64_t i = i0 + lane;
+      int g = i < e ? col_map[indices[i]] : -1;
+      bool keep = g >= 0;
+      uint64_t bal = __ballot(keep);
+      if (keep) {
+        int64_t pos = o + __popcll(bal & ((1ull << lane) - 1ull));
+        out_indices[pos] = g;
+        out_data[pos] = data[i];
+      }
+      o += __popcll(bal);
+    }
+  }
+}
+
+// per-gene totals of the CSR (fp64 atomics: counts are integers < 2^53, so the sums are exact whatever the order)
+__global__ __launch_bounds__(256) void k_csr_colsum(const int32_t *__restrict__ indices, const float *__restrict__ data, int64_t nnz,
+                                                    double *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) atomicAdd(out + indices[i], (double)data[i]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K0 step 1: nnz per (block, gene) with LDS counters; validates the counts.
 #define CNT_TILE 32768
@@ -752,6 +801,41 @@ int mm_csr_colsplit(const int64_t *d_indptr, const int32_t *d_indices, const flo
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_csr_colsplit, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_data, n_rows,
                      col_lo, col_hi, d_out_indptr, d_out_indices, d_out_data);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_csr_mapcount(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, const int32_t *d_col_map, int64_t *d_row_nnz,
+                    void *stream) {
+  MM_ARG(d_indptr && d_indices && d_col_map && d_row_nnz && n_rows >= 0);
+  if (n_rows == 0) return MM_OK;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_csr_mapcount, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, n_rows, d_col_map,
+                     d_row_nnz);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_csr_mapsplit(const int64_t *d_indptr, const int32_t *d_indices, const float *d_data, int64_t n_rows, const int32_t *d_col_map,
+                    const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_data, void *stream) {
+  MM_ARG(d_indptr && d_indices && d_data && d_col_map && d_out_indptr && d_out_indices && d_out_data && n_rows >= 0);
+  if (n_rows == 0) return MM_OK;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_csr_mapsplit, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indptr, d_indices, d_data, n_rows,
+                     d_col_map, d_out_indptr, d_out_indices, d_out_data);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_csr_colsum(const int32_t *d_indices, const float *d_data, int64_t nnz, double *d_out /* [n_genes], zeroed by the caller */,
+                  void *stream) {
+  MM_ARG(d_indices && d_data && d_out && nnz >= 0);
+  if (nnz == 0) return MM_OK;
+  int64_t blocks = (nnz + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_csr_colsum, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_indices, d_data, nnz, d_out);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -60,14 +60,59 @@ class Comm:
         return out
 
 
-def gather_1d_ht(comm, names, out):
+def gather_1d_ht(comm, names, out, gene_pos=None, n_tests=None):
     """Result gather of the gene-sharded 1D test: every rank contributes its genes' flat result vectors (gene-major x treatment,
-    reference order memento/main.py:399-404) and the names of its kept genes; since the shards are contiguous gene ranges in
-    rank order, the concatenation in rank order IS the unsharded run's ordering.  Returns (all names, dict of full vectors)."""
-    parts = comm.allgather_objects({"names": list(names), "out": {k: np.asarray(v) for k, v in out.items()}})
-    all_names = [n for p_ in parts for n in p_["names"]]
-    full = {k: np.concatenate([p_["out"][k] for p_ in parts]) for k in out}
-    return all_names, full
+    reference order memento/main.py:399-404), the names of its kept genes, their positions ``gene_pos`` in the UNSHARDED gene
+    order and the number of tests of each (``n_tests``; one per treatment column unless treatment_for_gene varies it).  The
+    genes of all ranks are put back in the unsharded order -- shards need not be contiguous ranges (cost-balanced shards are
+    not).  ``gene_pos`` None: contiguous shards in rank order (the concatenation in rank order is the unsharded order).
+    Returns (all names, dict of full vectors)."""
+    names = list(names)
+    k0 = next(iter(out))
+    if n_tests is None:
+        per = len(out[k0]) // max(1, len(names))
+        n_tests = np.full(len(names), per, dtype=np.int64)
+    parts = comm.allgather_objects({"names": names, "pos": None if gene_pos is None else np.asarray(gene_pos, dtype=np.int64),
+                                    "nt": np.asarray(n_tests, dtype=np.int64), "out": {k: np.asarray(v) for k, v in out.items()}})
+    if any(p_["pos"] is None for p_ in parts):
+        all_names = [n for p_ in parts for n in p_["names"]]
+        return all_names, {k: np.concatenate([p_["out"][k] for p_ in parts]) for k in out}
+    pos = np.concatenate([p_["pos"] for p_ in parts])
+    nt = np.concatenate([p_["nt"] for p_ in parts])
+    cat_names = np.array([n for p_ in parts for n in p_["names"]], dtype=object)
+    order = np.argsort(pos, kind="stable")
+    first = np.concatenate([[0], np.cumsum(nt)])[:-1]                    # first test of every gene in the rank-order concatenation
+    idx = np.concatenate([np.arange(first[g], first[g] + nt[g]) for g in order]) if len(order) else np.zeros(0, dtype=np.int64)
+    full = {k: np.concatenate([p_["out"][k] for p_ in parts])[idx] for k in out}
+    return cat_names[order].tolist(), full
+
+
+def shard_stream_uniforms(comm, gene_pos, live):
+    """The hash uniforms of this rank's chains out of the ONE global np.random stream of the unsharded run.
+
+    The reference takes two uniforms per live (gene, group) chain from the global stream, gene after gene in the unsharded order
+    (memento/bootstrap.py:62, :65; fan-out and scatter-back memento/main.py:379-404).  ``gene_pos`` [genes of this rank]: their
+    positions in that order; ``live`` [genes][groups] bool: chains that draw.  Every rank gathers (position, live chains) of all
+    genes, draws the whole stream -- identical on every rank, the caller seeds all ranks alike -- and keeps the entries at its
+    own chains' positions.  Returns (r1, r0), each [genes * groups] (0 where the chain is not live).  All ranks leave with the
+    global stream in the same state, as after the unsharded call."""
+    live = np.asarray(live, dtype=bool)
+    G, ng = live.shape
+    parts = comm.allgather_objects({"pos": np.asarray(gene_pos, dtype=np.int64), "live": live.sum(axis=1).astype(np.int64)})
+    pos = np.concatenate([p_["pos"] for p_ in parts])
+    nlive = np.concatenate([p_["live"] for p_ in parts])
+    order = np.argsort(pos, kind="stable")
+    start = np.empty(len(pos), dtype=np.int64)
+    start[order] = 2 * (np.cumsum(nlive[order]) - nlive[order])
+    first = sum(len(p_["pos"]) for p_ in parts[:comm.rank])
+    mine = start[first:first + G]
+    u = np.random.random(int(2 * nlive.sum()))
+    within = 2 * (np.cumsum(live, axis=1) - live)                 # [gene][group]: offset of a live chain inside its gene
+    at = (mine[:, None] + within).reshape(-1)
+    livef = live.reshape(-1)
+    r1, r0 = np.zeros(G * ng), np.zeros(G * ng)
+    r1[livef], r0[livef] = u[at[livef]], u[at[livef] + 1]
+    return r1, r0
 
 
 def gather_pair_results(comm, positions, values, n_total):
@@ -86,6 +131,32 @@ def shard_genes(n_genes, rank, world):
     lo = (n_genes * rank) // world
     hi = (n_genes * (rank + 1)) // world
     return lo, hi
+
+
+def gene_cost(mean, filter_mean_thresh=0.07):
+    """Predicted bootstrap cost of a gene from its mean count per cell (all a rank knows before the groups exist): genes below
+    the expression filter are never tested (memento/main.py:202-215) and cost next to nothing; a tested gene's chains have about
+    n_sf_bins x (distinct counts) bins, which grows like the spread of its counts -- ~sqrt(mean) on top of a floor."""
+    mean = np.asarray(mean, dtype=np.float64)
+    return np.where(mean >= 0.8 * filter_mean_thresh, 1.0 + 1.5 * np.sqrt(mean), 0.002)
+
+
+def shard_genes_balanced(cost, rank, world):
+    """Cost-balanced gene shard of ``rank`` (ascending gene indices): longest-processing-time-first over the predicted costs --
+    genes in descending cost, each to the rank with the least load so far (ties: the lowest rank) -- so that every rank gets the
+    same mix of long and short bootstrap chains.  A contiguous split (shard_genes) gives each rank whatever its range holds.
+    Deterministic: every rank computes the same assignment from the same costs."""
+    import heapq
+
+    cost = np.asarray(cost, dtype=np.float64)
+    order = np.argsort(-cost, kind="stable")
+    heap = [(0.0, r) for r in range(world)]
+    owner = np.empty(len(cost), dtype=np.int32)
+    for g in order:
+        load, r = heapq.heappop(heap)
+        owner[g] = r
+        heapq.heappush(heap, (load + cost[g], r))
+    return np.flatnonzero(owner == rank)
 
 
 def shard_pairs(gene_pairs, rank, world):

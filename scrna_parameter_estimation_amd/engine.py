@@ -146,6 +146,37 @@ class DeviceCSR:
         _lib.call("mm_csr_colsplit", P(self.indptr), P(self.indices), P(self.data), n, lo, hi, P(indptr), P(indices), P(data), _stream())
         return DeviceCSR.from_device(indptr, indices[:nnz], data[:nnz], (n, hi - lo))
 
+    def colselect(self, genes):
+        """The columns ``genes`` (ascending indices) as a new device CSR with columns renumbered 0..len(genes)-1: the gene SET
+        of a cost-balanced shard (mm_csr_mapcount + mm_csr_mapsplit)."""
+        torch = _torch()
+        genes = np.asarray(genes, dtype=np.int64)
+        if len(genes) and (np.diff(genes) <= 0).any():
+            raise ValueError("gene indices must ascend")
+        if len(genes) and not (0 <= genes[0] and genes[-1] < self.shape[1]):
+            raise ValueError("gene index out of bounds")
+        n = self.shape[0]
+        col_map = np.full(self.shape[1], -1, dtype=np.int32)
+        col_map[genes] = np.arange(len(genes), dtype=np.int32)
+        d_map = dev(col_map)
+        row_nnz = empty((max(1, n),), torch.int64)
+        _lib.call("mm_csr_mapcount", P(self.indptr), P(self.indices), n, P(d_map), P(row_nnz), _stream())
+        indptr = zeros((n + 1,), torch.int64)
+        if n:
+            indptr[1:] = torch.cumsum(row_nnz[:n], 0)
+        nnz = int(indptr[-1].item())
+        indices = empty((max(1, nnz),), torch.int32)
+        data = empty((max(1, nnz),), torch.float32)
+        _lib.call("mm_csr_mapsplit", P(self.indptr), P(self.indices), P(self.data), n, P(d_map), P(indptr), P(indices), P(data), _stream())
+        return DeviceCSR.from_device(indptr, indices[:nnz], data[:nnz], (n, len(genes)))
+
+    def colsum(self):
+        """Per-gene totals (host array): what the cost-balanced gene sharding is computed from."""
+        torch = _torch()
+        out = zeros((max(1, self.shape[1]),), torch.float64)
+        _lib.call("mm_csr_colsum", P(self.indices), P(self.data), self.nnz, P(out), _stream())
+        return host(out)[: self.shape[1]]
+
     def rowsum(self, gene_mask=None):
         """K3: per-cell sums, optionally over a gene mask (estimator.py:65, :73)."""
         torch = _torch()

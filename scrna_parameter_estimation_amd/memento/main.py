@@ -121,15 +121,20 @@ def _plain_means(blocks, sumx, n_cells, thresh, kind):
 
 
 def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_percent=0.1, shrinkage=0.5, num_bins=30,
-                  estimator_type='hyper_relative', *, device_csr=None, comm=None, shard=False):
+                  estimator_type='hyper_relative', *, device_csr=None, comm=None, shard=False, size_factor=None):
     """Compute size factors and the all-cell moments (reference: memento/main.py:26-91).
 
     Extensions: ``device_csr`` -- an ``engine.DeviceCSR`` already resident in HBM (``adata.X`` is then only
     used for its shape); ``comm`` -- a ``dist.Comm`` when the GENES are sharded over ranks (every rank holds
     all cells x its gene shard): per-cell totals are all-reduced so every rank gets the global size factors.
-    ``shard=True`` (with ``comm``): ``adata`` holds ALL genes on every rank; this rank's contiguous gene range is cut out
-    of the resident CSR on the device (mm_csr_colsplit) -- no host-side ``X[:, lo:hi]`` -- and the later calls work on
-    that shard (``adata`` itself is left whole; ``uns['memento']['gene_list']`` etc. name the shard's genes)."""
+    ``shard=True`` (with ``comm``): ``adata`` holds ALL genes on every rank; this rank's genes are cut out of the resident CSR
+    on the device -- no host-side ``X[:, genes]`` -- and the later calls work on that shard (``adata`` itself is left whole;
+    ``uns['memento']['gene_list']`` etc. name the shard's genes).  ``shard=True`` / ``'balanced'``: a cost-balanced gene SET
+    (``dist.shard_genes_balanced`` over the predicted chain cost of every gene, from the per-gene totals of the resident matrix:
+    each rank gets the same mix of long and short bootstrap chains); ``'contiguous'``: the range ``dist.shard_genes`` gives.
+    ``shard=<array>``: ``adata`` already holds only this rank's genes, at these positions of the unsharded gene order.
+    ``size_factor`` -- precomputed size factors (N values, e.g. those of the whole matrix when ``adata`` is a gene subset):
+    the estimation of estimator.py:49-81 is skipped and they are used as they are."""
     if not inplace:
         adata = adata.copy()
     assert adata.obs[q_column].max() < 1
@@ -152,16 +157,37 @@ def setup_memento(adata, q_column, inplace=True, filter_mean_thresh=0.07, trim_p
     assert tuple(st.csr.shape) == (N, G)
     names0 = np.asarray(adata.var.index)
     st.shard = None
-    if shard:
+    if isinstance(shard, (np.ndarray, list, tuple)):
+        # the caller pre-sliced X: these are the positions of adata's genes in the unsharded gene order (needed to put the
+        # gathered results, and the global np.random stream, back in that order)
+        st.shard = np.asarray(shard, dtype=np.int64)
+        assert st.shard.shape == (G,)
+    elif shard:
         if comm is None:
             raise ValueError("shard=True needs comm")
-        from ..dist import shard_genes
-        lo, hi = shard_genes(G, comm.rank, comm.world)
-        st.csr = st.csr.colsplit(lo, hi)             # device-side column split; the full CSR is released
-        st.shard = (lo, hi)
-        st.var_names = names0 = names0[lo:hi]
-        G = hi - lo
+        from ..dist import gene_cost, shard_genes, shard_genes_balanced
+        if shard == 'contiguous':
+            lo, hi = shard_genes(G, comm.rank, comm.world)
+            mine = np.arange(lo, hi)
+            st.csr = st.csr.colsplit(lo, hi)         # device-side column split; the full CSR is released
+        else:
+            mine = shard_genes_balanced(gene_cost(st.csr.colsum() / N, filter_mean_thresh), comm.rank, comm.world)
+            st.csr = st.csr.colselect(mine)
+        st.shard = mine                              # this rank's genes: positions in the unsharded gene order (ascending)
+        st.var_names = names0 = names0[mine]
+        G = len(mine)
     st.gene_idx = np.arange(G)
+    if size_factor is not None:
+        size_factor = np.asarray(size_factor, dtype=np.float64)
+        assert size_factor.shape == (N,)
+        adata.obs['memento_size_factor'] = size_factor
+        m['least_variable_genes'] = []
+        blocks_all = engine.CountBlocks(st.csr, np.zeros(N, dtype=np.int32), 1)
+        S, _, _ = blocks_all.moments(1.0 / size_factor)
+        m['all_1d_moments'] = list(_moments_from_sums(S[:, 0], N, m['all_q']))
+        if estimator_type == 'mean_only':
+            m['all_1d_moments'] = [m['all_1d_moments'][0] + 1, np.ones(G) * 10]
+        return adata if not inplace else None
     naive = st.csr.rowsum()                                                   # estimator.py:64-69
     if comm is not None:
         naive = comm.allreduce_sum(naive)
@@ -289,7 +315,7 @@ def compute_1d_moments(adata, inplace=True, min_perc_group=0.7, filter_genes=Tru
     S, sumx, maxx = st.blocks.moments(1.0 / adata.obs['memento_size_factor'].values)          # K1+K2
     cur = st.gene_idx                                    # columns of the device blocks that adata currently holds
     names_cur = _var_names(adata)
-    if getattr(st, 'shard', None) is not None:
+    if getattr(st, 'shard', None) is not None and adata.shape[1] != st.csr.shape[1]:
         subset_var = False                               # adata holds all genes of all ranks; only the shard's names move
     mean = S[0][:, cur] / Nc[:, None]
     var = S[1][:, cur] / Nc[:, None] - (1 - gq)[:, None] * S[2][:, cur] / Nc[:, None] - mean ** 2
@@ -479,7 +505,10 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 draw_assignments(gi)
 
         if not strict:
-            draw_stream(0)
+            if shard_stream is not None:      # gene-sharded: this rank's slice of the ONE global stream (see below)
+                r1[:], r0[:] = shard_stream[0][g0 * ng:g1 * ng], shard_stream[1][g0 * ng:g1 * ng]
+            else:
+                draw_stream(0)
             n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
             bad_fill = (n_inv < 0).any(axis=1)
             # how much of the result depends on the device refill (strict=True replays the reference's own _fill draws instead):
@@ -626,6 +655,25 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         return out
 
     G_all = len(st.gene_idx)
+    comm = getattr(st, 'comm', None)
+    sharded = comm is not None and comm.world > 1
+    shard_stream = gene_pos = None
+    if sharded:
+        # The reference scatters every gene's result back from ONE sequential np.random stream (main.py:399-404, bootstrap.py:62-65):
+        # two hash uniforms per live (gene, group) chain, gene-major.  A rank must therefore use the uniforms at the positions its
+        # genes have in the UNSHARDED order: gather (position, live chains) of every kept gene, draw the whole stream (the same
+        # on every rank: the caller seeds all ranks alike) and keep this rank's entries.  N-rank results then equal 1-rank results.
+        if strict:
+            raise NotImplementedError("strict=True replays the reference's _fill draws, which shift the global stream gene after "
+                                      "gene: it is sequential over all genes -- run it on one rank")
+        shard = getattr(st, 'shard', None)
+        if shard is not None:
+            gene_pos = np.asarray(shard, dtype=np.int64)[st.gene_idx]
+        else:                               # the caller pre-sliced X: contiguous blocks in rank order
+            sizes = comm.allgather_objects(int(st.csr.shape[1]))
+            gene_pos = int(sum(sizes[:comm.rank])) + np.asarray(st.gene_idx, dtype=np.int64)
+        from ..dist import shard_stream_uniforms
+        shard_stream = shard_stream_uniforms(comm, gene_pos, (~_pair_skip(true_mean, true_rv)).reshape(G_all, ng))
     st.refill_stats = dict(chains=0, chains_refilled=0, genes=0, genes_refilled=0, gene_refilled=np.zeros(G_all, dtype=bool))
     st.last_bootstrap = None                   # the previous call's replicate rows (GBs) go back to the caching allocator BEFORE this call allocates its own
     if max_rows is None:                       # replicate buffers sized to the free HBM (288 GB on MI355X)
@@ -635,12 +683,14 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
     keys = ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')
     out = {k: (np.concatenate([p_[k] for p_ in parts]) if parts else np.zeros(0)) for k in keys}
     m['1d_ht'] = {}
-    comm = getattr(st, 'comm', None)
-    if comm is not None and comm.world > 1:
+    if sharded:
         # gene-sharded run: scatter-back of the reference (main.py:399-412) across ranks -- every rank ends with the flat result
         # vectors of ALL genes in the unsharded run's order, plus the gene names they belong to
         from ..dist import gather_1d_ht
-        m['1d_ht']['gene_names'], out = gather_1d_ht(comm, names, out)
+        nt_gene = (np.full(G_all, trt_all.shape[1], dtype=np.int64) if treatment_for_gene is None
+                   else np.array([len(treatment_for_gene[n_]) for n_ in names[:G_all]], dtype=np.int64))
+        st.local_ht = {k: np.asarray(v).copy() for k, v in out.items()}          # this rank's own tests (bench: per-rank accounting)
+        m['1d_ht']['gene_names'], out = gather_1d_ht(comm, names, out, gene_pos=gene_pos, n_tests=nt_gene)
     if treatment_for_gene is not None:
         m['1d_ht']['treatment_for_gene'] = treatment_for_gene
     m['1d_ht']['treatment'] = treatment

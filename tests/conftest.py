@@ -83,6 +83,11 @@ def guide_loop():
     return load_golden("guide_loop")
 
 
+@pytest.fixture(scope="session")
+def guide_loop_small():
+    return load_golden("guide_loop_small")
+
+
 def golden_inputs(g):
     """Rebuild (X csr float64, group_id, n_groups, q) from a golden api_* fixture."""
     import scipy.sparse as sp

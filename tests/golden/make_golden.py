@@ -486,6 +486,44 @@ def c1_case(name):
     print(name, "genes kept", int(out["overall_gene_filter"].sum()), "finite p", np.isfinite(out["ht_mean_asl"]).sum())
 
 
+def guide_loop_small_case(name):
+    """The same per-guide loop with SMALL guide groups (~150-350 cells, the size of BASELINE.json configs[4]'s 320-cell guides) and
+    sparse genes, so that a good part of the (gene, guide) tests cannot be done: the reference drops a gene from a guide's
+    two-group subset when its expression filter (plain mean > 0.07 and variance estimate > 0, in both groups: main.py:202-215 with
+    min_perc_group=0.9) fails, and returns NaN when a group's moments are not usable (hypothesis_test.py:167-171).  Fixture for
+    checking WHICH tests the batched ht_1d_vs_control reports as NaN."""
+    from scrna_parameter_estimation_amd.anndata_lite import AnnDataLite
+    import copy
+
+    n_guides = 10
+    adata = synth_adata(3200, 140, 0.07, 1, 1, 171, dtype=np.float64)
+    rng = np.random.default_rng(172)
+    guide = rng.choice(n_guides + 1, size=adata.shape[0], p=np.r_[0.25, np.full(n_guides, 0.075)])
+    adata.obs["guide"] = guide
+    inp = dict(indptr=adata.X.indptr.copy(), indices=adata.X.indices.copy(), data=adata.X.data.copy(), shape=np.array(adata.X.shape),
+               guide=guide.astype(np.int64), q=adata.obs["q"].values.copy(), gene_names=np.array(adata.var.index.tolist()))
+    memento.setup_memento(adata, q_column="q")
+    out = {"size_factor": adata.obs["memento_size_factor"].values.copy(), "n_guides": np.int64(n_guides)}
+    for gid in range(1, n_guides + 1):
+        rows = np.flatnonzero((guide == 0) | (guide == gid))
+        sub = AnnDataLite(adata.X[rows].tocsr(), adata.obs.iloc[rows].copy(), adata.var.copy(), copy.deepcopy(adata.uns))
+        sub.obs["is_guide"] = (sub.obs["guide"].values == gid).astype(int)
+        memento.create_groups(sub, label_columns=["is_guide"])
+        memento.compute_1d_moments(sub, min_perc_group=0.9)
+        gdf = memento.get_groups(sub)
+        cov = pd.DataFrame({"intercept": np.ones(len(gdf))}, index=gdf.index)
+        trt = pd.DataFrame({"is_guide": gdf["is_guide"].astype(float).values}, index=gdf.index)
+        np.random.seed(180 + gid)
+        memento.ht_1d_moments(sub, covariate=cov, treatment=trt, num_boot=200, num_cpus=1, verbose=0, resampling="bootstrap", approx=True)
+        ht = sub.uns["memento"]["1d_ht"]
+        out[f"g{gid}_genes"] = np.array(sub.var.index.tolist())
+        out[f"g{gid}_cells"] = np.int64((guide == gid).sum())
+        for k in ["mean_coef", "mean_se", "mean_asl", "var_coef", "var_se", "var_asl"]:
+            out[f"g{gid}_{k}"] = np.asarray(ht[k]).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{("in_" + k): v for k, v in inp.items()}, **out)
+    print(name, [(int(out[f"g{g}_cells"]), len(out[f"g{g}_genes"]), int(np.isnan(out[f"g{g}_mean_asl"]).sum())) for g in range(1, n_guides + 1)])
+
+
 def guide_loop_case(name):
     """The reference's Perturb-seq pattern on the current API (analysis/sciplex/sciplex_dv.py:18-40 style): for every guide,
     subset to control + guide cells, create_groups, compute_1d_moments, ht_1d_moments.  Fixture for measuring how far the
@@ -522,8 +560,61 @@ def guide_loop_case(name):
     print(name, [len(out[f"g{g}_genes"]) for g in range(1, n_guides + 1)])
 
 
+def simulate_case(name, seed):
+    """memento/simulate.py of the real reference: the deterministic ``extract_parameters`` (:13-33) on a
+    small CSR, and seeded SAMPLES of ``simulate_transcriptomes`` (:52-89; independent negative binomials and the Gaussian copula
+    with a given covariance) and ``capture_sampling`` (:91-115; hypergeometric and Poisson capture) from those parameters --
+    what the device generator (memento.simulate, csrc/simulate.hip: own random numbers) is compared with, distribution by
+    distribution."""
+    import memento.simulate as rsim
+
+    adata = synth_adata(4000, 48, 0.35, 1, 1, seed, dtype=np.float64)
+    X = adata.X
+    # extract_parameters as shipped raises TypeError: it calls estimator._estimate_size_factor(data, 'hyper_relative', total=True)
+    # without the positional ``shrinkage`` (simulate.py:23 vs estimator.py:49).  With total=True and no mask that function never reads
+    # shrinkage (estimator.py:64-69: the raw row sums), so the argument is supplied for the duration of this call -- nothing else
+    # of the reference is touched.
+    orig = rsim.estimator._estimate_size_factor
+    rsim.estimator._estimate_size_factor = lambda data, et, total=False: orig(data, et, 0.5, total=total)
+    try:
+        (x_mean, x_var), (z_mean, z_var), Nc, good_idx = rsim.extract_parameters(X, q=0.1, min_mean=0.001)
+    finally:
+        rsim.estimator._estimate_size_factor = orig
+    out = dict(in_data=X.data, in_indices=X.indices, in_indptr=X.indptr, in_shape=np.array(X.shape), q=0.1, min_mean=0.001,
+               x_mean=x_mean, x_var=x_var, z_mean=z_mean, z_var=z_var, Nc=Nc, good_idx=good_idx)
+    n_cells = 4000
+    G = len(good_idx)
+    # the simulation parameters: moderately expressed, over-dispersed genes (the reference's notebooks feed it extract_parameters'
+    # output of a real dataset; these keep the fixture small and every branch busy)
+    rng = np.random.default_rng(seed + 1)
+    means = rng.lognormal(1.0, 0.8, size=G)
+    variances = means + means ** 2 * rng.uniform(0.1, 1.0, size=G)
+    out.update(sim_means=means, sim_variances=variances, n_cells=n_cells)
+    np.random.seed(seed + 2)
+    indep = rsim.simulate_transcriptomes(n_cells, means.copy(), variances.copy(), Nc, norm_cov="indep")
+    out["indep"] = indep.astype(np.int32)
+    # Gaussian copula with a given covariance: neighbouring genes correlate (rho^|i-j|), unequal scales
+    rho, sd = 0.7, rng.uniform(0.5, 2.0, size=G)
+    corr = rho ** np.abs(np.subtract.outer(np.arange(G), np.arange(G)))
+    cov = corr * np.outer(sd, sd)
+    np.random.seed(seed + 3)
+    cop = rsim.simulate_transcriptomes(n_cells, means.copy(), variances.copy(), Nc, norm_cov=cov.copy())
+    out.update(norm_cov=cov, copula=cop.astype(np.int32))
+    for proc in ("hyper", "poisson"):
+        np.random.seed(seed + 4)
+        qs, cap = rsim.capture_sampling(indep, 0.1, process=proc)
+        out[f"cap_{proc}"] = np.asarray(cap).astype(np.int32)
+        out[f"qs_{proc}"] = np.asarray(qs)
+    np.random.seed(seed + 5)
+    qs, cap = rsim.capture_sampling(indep, 0.1, q_sq=0.012, process="hyper")       # Beta-distributed capture rates
+    out.update(cap_beta=np.asarray(cap).astype(np.int32), qs_beta=np.asarray(qs), q_sq=0.012)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: np.asarray(v).shape for k, v in out.items() if np.ndim(v) > 0})
+
+
 if __name__ == "__main__":
-    only = {"corrmat": lambda: corrmat_case("corrmat_negvar", seed=7), "rr16": lambda: rr16_case("api_rr16", seed=51, num_boot=300, two_d_pairs=10),
+    only = {"simulate": lambda: simulate_case("simulate_ref", seed=61), "guides_small": lambda: guide_loop_small_case("guide_loop_small"),
+            "corrmat": lambda: corrmat_case("corrmat_negvar", seed=7), "rr16": lambda: rr16_case("api_rr16", seed=51, num_boot=300, two_d_pairs=10),
             "c1": lambda: c1_case("api_c1"), "guides": lambda: guide_loop_case("guide_loop"),
             "tfg2d": lambda: tfg2d_case("api_tfg2d", num_boot=300, ht_seed=33)}
     if len(sys.argv) == 2 and sys.argv[1] in only:      # the round-2 fixtures (each reproducible on its own)

@@ -189,6 +189,32 @@ out = {"mean_coef": np.concatenate([np.full(ntest[i], mean[i]) for i in mine]) i
 gn, full = gather_1d_ht(c, [names_all[i] for i in mine], out)
 assert gn == [names_all[i] for i in range(G) if kept[i]]
 assert np.array_equal(full["mean_coef"], coef_all) and len(full["mean_asl"]) == len(coef_all)
+# cost-balanced (non-contiguous) shards: every gene owned once, loads level; the gather puts results back in the unsharded order
+from scrna_parameter_estimation_amd.dist import gene_cost, shard_genes_balanced, shard_stream_uniforms
+cost = gene_cost(mean)
+sh = [shard_genes_balanced(cost, r_, world) for r_ in range(world)]
+assert sorted(np.concatenate(sh).tolist()) == list(range(G)) and all((np.diff(x) > 0).all() for x in sh)
+loads = [cost[x].sum() for x in sh]
+assert max(loads) - min(loads) <= cost.max()
+bal = [i for i in sh[rank] if kept[i]]
+outb = {"mean_coef": np.concatenate([np.full(ntest[i], mean[i]) for i in bal]) if bal else np.zeros(0),
+        "mean_asl": np.concatenate([np.full(ntest[i], var[i]) for i in bal]) if bal else np.zeros(0)}
+gnb, fullb = gather_1d_ht(c, [names_all[i] for i in bal], outb, gene_pos=np.array(bal, dtype=np.int64), n_tests=ntest[bal])
+assert gnb == [names_all[i] for i in range(G) if kept[i]] and np.array_equal(fullb["mean_coef"], coef_all)
+# the hash uniforms of a rank's chains come from the ONE global stream at the chains' unsharded positions (identical seeds)
+ng_ = 3
+live_all = rng.random((G, ng_)) < 0.8
+kept_idx = np.flatnonzero(kept)
+np.random.seed(11)
+u_ref = np.random.random(2 * int(live_all[kept_idx].sum()))                 # the unsharded run: gene-major over the kept genes
+state_ref = np.random.get_state()[1].copy()
+ref1, ref0 = np.zeros((G, ng_)), np.zeros((G, ng_))
+gg, jj = np.nonzero(live_all[kept_idx])                                      # row-major = gene-major, group by group
+ref1[kept_idx[gg], jj], ref0[kept_idx[gg], jj] = u_ref[0::2], u_ref[1::2]
+np.random.seed(11)
+r1_, r0_ = shard_stream_uniforms(c, np.array(bal, dtype=np.int64), live_all[bal])
+assert np.array_equal(r1_.reshape(-1, ng_), ref1[bal]) and np.array_equal(r0_.reshape(-1, ng_), ref0[bal])
+assert np.array_equal(np.random.get_state()[1], state_ref)                 # every rank leaves the stream where the unsharded run does
 # 2D: pair blocks from shard_pairs, results back in the caller's order on every rank
 pairs = [(names_all[int(a)], names_all[int(b)]) for a, b in rng.integers(0, G, size=(37, 2))]
 blk, pos = shard_pairs(pairs, rank, world)

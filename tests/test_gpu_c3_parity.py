@@ -2,8 +2,8 @@
 groups) with **B = 10,000** bootstraps, ``approx=False``, through ``memento.ht_1d_moments`` exactly as ``bench.py`` times it
 (default packing: the long chains one per wave, the rest in tiles, three tile waves per SIMD).
 
-For eight genes -- the one holding the longest chain, the two with the smallest p-values (extreme count <= 10: the
-genextreme tail-fit branch of hypothesis_test.py:57-141), five typical ones -- the oracle (oracle/memento_oracle.py, pinned to
+For eight genes -- the one holding the longest chain, the two with the smallest p-values (the smallest has an extreme count
+<= 10: the genextreme tail-fit branch of hypothesis_test.py:57-141), five typical ones -- the oracle (oracle/memento_oracle.py, pinned to
 the real reference by tests/test_oracle_golden.py) is run on the same counts with the same hash uniforms (the global np.random
 stream hands two to every live (gene, group) chain, gene-major: bootstrap.py:62, :65) and must agree: log replicate moments
 1e-11 / 1e-9, coefficients and standard errors 1e-8, p-values 1e-5 (hypothesis_test.py:144-215)."""
@@ -74,7 +74,7 @@ def test_c3_headline_config_pvalues_match_the_oracle_at_10000_bootstraps():
     groups = m["groups"]
     kept = st.gene_idx
     assert bs.n_pairs == len(kept) * ng, "one chunk expected at C3 (replicate rows fit in HBM)"
-    assert bs.n_tiles > 2048 and bs.n_chain > 0                 # the bench's packing: both kernels, three tile waves per SIMD
+    assert bs.n_tiles > 2048 and bs.n_chain > 0                 # the bench's packing: three waves per SIMD, lone chains run wave-uniform
     assert st.refill_stats["chains_refilled"] == 0              # timed mode == reference-pinned mode at C3 (no invalid replicate)
     ht = m["1d_ht"]
     tm = np.stack([m["1d_moments"][g][0] for g in groups])
@@ -85,7 +85,7 @@ def test_c3_headline_config_pvalues_match_the_oracle_at_10000_bootstraps():
     g_long = int(np.argmax(Kg.max(axis=1)))
     pmin = np.minimum(ht["mean_asl"], ht["var_asl"])
     small = [int(i) for i in np.argsort(pmin)[:2]]
-    assert pmin[small[1]] < 11.5 / (B + 1), "expected two genes beyond the exact-count range (tail-fit branch)"
+    assert pmin[small[0]] < 11.5 / (B + 1), "expected a gene beyond the exact-count range (extreme count <= 10: tail-fit branch)"
     rest = [int(i) for i in np.random.default_rng(5).choice(len(kept), size=12, replace=False) if i not in (g_long, *small)][:5]
     genes = [g_long] + small + rest
     cols = bench.sample_columns(csr, kept[genes], torch).astype(np.float32)       # [N][8] dense

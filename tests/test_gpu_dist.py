@@ -1,7 +1,11 @@
 """Gene-sharded execution (one process per rank) gives the unsharded -- i.e. the real reference's --
 results: two ranks (gloo rendezvous, both on cuda:0) each hold all cells x half of the genes of the api_small fixture.
-Both ways in: the caller pre-slices X on the host, or (``shard=True``) hands the FULL matrix to every rank and the gene range
-is cut out on the device (mm_csr_colsplit).  ht_1d_moments ends with the gather: every rank holds the full result vectors in
+Both ways in: the caller pre-slices a contiguous gene range of X on the host, or (``shard=True``) hands the FULL matrix to every
+rank and a COST-BALANCED gene set (not a range) is cut out on the device (mm_csr_colsum + mm_csr_mapsplit).  Every rank is
+seeded alike and takes its chains' hash uniforms from the one global np.random stream at their unsharded positions, so the
+gathered standard errors and p-values are those of the 1-rank run -- and the real reference's up to the first gene whose
+invalid replicates the reference re-fills from that stream (the timed mode re-fills on the device).  A second test drives the
+same exchanges over the nccl (= RCCL) backend on cuda tensors.  ht_1d_moments ends with the gather: every rank holds the full result vectors in
 the unsharded run's gene order (the scatter-back of memento/main.py:399-412).  2D: pair blocks from dist.shard_pairs, results
 reassembled in the caller's pair order."""
 
@@ -41,13 +45,15 @@ m = adata.uns["memento"]
 gdf = memento.get_groups(adata)
 cov = pd.DataFrame(g["covariate"], index=gdf.index, columns=["intercept"])
 trt = pd.DataFrame(g["treatment"], index=gdf.index, columns=["cond"])
-np.random.seed(1 + comm.rank)
-memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=100, num_cpus=1, verbose=0, resampling="bootstrap", approx=True)
+np.random.seed(int(g["ht_seed"]))                      # the SAME seed on every rank
+memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0, resampling="bootstrap",
+                      approx=bool(g["approx"]))
 groups = m["groups"]
 np.savez(os.path.join(%(out)r, f"rank{comm.rank}.npz"), size_factor=adata.obs["memento_size_factor"].values,
          gene_list=np.array(m["gene_list"]), mean=np.stack([m["1d_moments"][k][0] for k in groups]),
          res_var=np.stack([m["1d_moments"][k][2] for k in groups]), mv=np.asarray(m["mv_regressor"]["all"]),
          mean_coef=m["1d_ht"]["mean_coef"], var_coef=m["1d_ht"]["var_coef"], ht_names=np.array(m["1d_ht"]["gene_names"]),
+         mean_se=m["1d_ht"]["mean_se"], mean_asl=m["1d_ht"]["mean_asl"], var_se=m["1d_ht"]["var_se"], var_asl=m["1d_ht"]["var_asl"],
          df_genes=np.array(memento.get_1d_ht_result(adata)["gene"].tolist()))
 # 2D on pair blocks (every rank needs all genes' columns: a second, unsharded state on the same device)
 from scrna_parameter_estimation_amd.dist import shard_pairs, gather_pair_results
@@ -88,15 +94,46 @@ def test_two_gene_shards_equal_the_unsharded_reference(api_small, tmp_path, devi
     for p in parts:                                              # every rank ends with the GLOBAL size factors and the pooled fit
         np.testing.assert_allclose(p["size_factor"], g["size_factor"], rtol=1e-12)
         np.testing.assert_allclose(p["mv"], g["mv_regressor"], rtol=1e-8)
-    assert list(parts[0]["gene_list"]) + list(parts[1]["gene_list"]) == list(g["gene_list"])
-    np.testing.assert_allclose(np.concatenate([p["mean"] for p in parts], axis=1), g["mean"], rtol=1e-11)
-    np.testing.assert_allclose(np.concatenate([p["res_var"] for p in parts], axis=1), g["res_var"], rtol=1e-7, equal_nan=True)
+    # the two shards partition the kept genes (contiguous halves when pre-sliced; a cost-balanced, interleaved split on the device)
+    both = list(parts[0]["gene_list"]) + list(parts[1]["gene_list"])
+    assert sorted(both) == sorted(g["gene_list"])
+    if not device_split:
+        assert both == list(g["gene_list"])
+    else:
+        assert both != list(g["gene_list"]), "cost-balanced shards are gene sets, not ranges"
+    at = {n: i for i, n in enumerate(both)}
+    back = [at[n] for n in g["gene_list"]]                                              # unsharded order
+    np.testing.assert_allclose(np.concatenate([p["mean"] for p in parts], axis=1)[:, back], g["mean"], rtol=1e-11)
+    np.testing.assert_allclose(np.concatenate([p["res_var"] for p in parts], axis=1)[:, back], g["res_var"], rtol=1e-7, equal_nan=True)
     # the gather: EVERY rank holds the full result vectors, in the unsharded gene order; observed coefficients do not depend on
     # the bootstrap draws, so they are the real reference's
     for p in parts:
         assert list(p["ht_names"]) == list(g["gene_list"]) and list(p["df_genes"]) == list(g["gene_list"])
         np.testing.assert_allclose(p["mean_coef"], g["ht_mean_coef"], rtol=1e-8, atol=1e-12, equal_nan=True)
         np.testing.assert_allclose(p["var_coef"], g["ht_var_coef"], rtol=1e-7, atol=1e-12, equal_nan=True)
+    # N-rank results == 1-rank results: the same call unsharded, in this process, on the same seed.  The mean statistics do not
+    # depend on the pooled mean-variance fit and agree to round-off; the variability statistics see the fit, which the ranks
+    # compute from the gathered moments in another order (np.polyfit: ~1e-9 relative).
+    from test_gpu_api import _design, _run_to_moments
+    memento, adata = _run_to_moments(g)
+    cov, trt = _design(memento, adata, g)
+    np.random.seed(int(g["ht_seed"]))
+    memento.ht_1d_moments(adata, covariate=cov, treatment=trt, num_boot=int(g["num_boot"]), num_cpus=1, verbose=0, resampling="bootstrap",
+                          approx=bool(g["approx"]))
+    one = adata.uns["memento"]["1d_ht"]
+    refilled = adata.uns["memento"]["_hip"].refill_stats["gene_refilled"]
+    for p in parts:
+        for k in ("mean_coef", "mean_se", "mean_asl"):
+            np.testing.assert_allclose(p[k], one[k], rtol=1e-12, atol=1e-14, equal_nan=True, err_msg=k)
+        for k in ("var_coef", "var_se", "var_asl"):
+            np.testing.assert_allclose(p[k], one[k], rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=k)
+    # ... and the real reference's standard errors and p-values for every gene in front of the first one whose invalid replicates
+    # the reference re-fills from the global stream (behind it the reference's hash uniforms are shifted; strict=True replays that)
+    first_fill = int(np.argmax(refilled)) if refilled.any() else len(refilled)
+    assert first_fill >= 10, first_fill
+    for p in parts:
+        for k, tol in (("mean_se", 1e-8), ("var_se", 1e-6), ("mean_asl", 1e-5), ("var_asl", 1e-5)):
+            np.testing.assert_allclose(p[k][:first_fill], g["ht_" + k][:first_fill], rtol=tol, atol=1e-12, equal_nan=True, err_msg=k)
     # 2D: pair blocks reassembled in the caller's order == the unsharded fixture (moments exactly; observed coefficients too)
     pr = [dict(np.load(tmp_path / f"pairs_rank{k}.npz")) for k in range(2)]
     for p in pr:
@@ -106,3 +143,49 @@ def test_two_gene_shards_equal_the_unsharded_reference(api_small, tmp_path, devi
         # is tested on both, with the same observed coefficient
         ok = np.isfinite(g["ht2_corr_coef"])
         np.testing.assert_allclose(p["corr_coef"][ok], g["ht2_corr_coef"][ok], rtol=1e-8, atol=1e-12)
+
+
+NCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, pandas as pd, scipy.sparse as sp
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+from scrna_parameter_estimation_amd import AnnDataLite, memento
+from scrna_parameter_estimation_amd.dist import Comm
+comm = Comm()
+assert comm.device == "cuda" and dist.get_backend() == "nccl"
+a = comm.allreduce_sum(np.arange(5.0))                       # RCCL all-reduce / all-gather on cuda tensors
+b = comm.allgather_concat(np.arange(3.0) + comm.rank)
+assert a.tolist() == (np.arange(5.0) * comm.world).tolist() and len(b) == 3 * comm.world
+g = dict(np.load(os.path.join(%(root)r, "tests", "golden", "api_small.npz"), allow_pickle=False))
+X = sp.csr_matrix((g["in_data"].astype(np.float32), g["in_indices"], g["in_indptr"]), shape=tuple(g["in_shape"]))
+obs = pd.DataFrame({"cond": g["in_cond"], "rep": g["in_rep"], "q": g["in_q"]}, index=[f"c{i}" for i in range(X.shape[0])])
+adata = AnnDataLite(X, obs, pd.DataFrame(index=g["in_gene_names"].tolist()))
+memento.setup_memento(adata, q_column="q", comm=comm, shard=True)          # size factors through all-reduce, pooled fit through all-gather
+memento.create_groups(adata, label_columns=["cond", "rep"])
+memento.compute_1d_moments(adata, min_perc_group=0.7)
+m = adata.uns["memento"]
+np.savez(os.path.join(%(out)r, "nccl.npz"), size_factor=adata.obs["memento_size_factor"].values, mv=np.asarray(m["mv_regressor"]["all"]),
+         gene_list=np.array(m["gene_list"]), mean=np.stack([m["1d_moments"][k][0] for k in m["groups"]]))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_exchanges_run_over_nccl_on_cuda_tensors(api_small, tmp_path):
+    """torch.distributed backend "nccl" (= RCCL on ROCm), one rank: Comm's all-reduce and all-gather run on cuda tensors inside
+    setup_memento / compute_1d_moments (the backend of the multi-GPU bench); results equal the real reference's."""
+    g = api_small
+    script = tmp_path / "nccl.py"
+    script.write_text(NCCL_SCRIPT % {"root": ROOT, "out": str(tmp_path)})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = dict(np.load(tmp_path / "nccl.npz"))
+    np.testing.assert_allclose(out["size_factor"], g["size_factor"], rtol=1e-12)
+    np.testing.assert_allclose(out["mv"], g["mv_regressor"], rtol=1e-8)
+    assert list(out["gene_list"]) == list(g["gene_list"])
+    np.testing.assert_allclose(out["mean"], g["mean"], rtol=1e-11)

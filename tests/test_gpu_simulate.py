@@ -1,6 +1,7 @@
 """Device simulator (memento.simulate, csrc/simulate.hip; reference memento/simulate.py:52-68, :91-115).  Draw-level parity with
 numpy / scipy is unpinned by construction (own counter-based generators): the checks are exact structural invariants of the
-capture process plus statistical agreement with the distributions the reference samples, and -- the reference's own acceptance
+capture process, statistical agreement with the distributions the reference samples -- incl. seeded samples of the REAL
+reference's simulate.py (fixture simulate_ref, bottom of this file), whose deterministic extract_parameters is matched to 1e-9 -- and -- the reference's own acceptance
 test (analysis/simulation/estimator_validation.ipynb) -- recovery of the simulated moments through the HIP estimators."""
 
 import numpy as np
@@ -185,3 +186,87 @@ def test_copula_transcriptomes_cell_sizes_and_dependence():
     assert np.allclose(S, S.T) and np.linalg.eigvalsh(S).min() > 0
     t2 = simulate.simulate_transcriptomes(2000, means[:12], variances[:12], Nc, seed=6)
     assert _dense(t2.to_device_csr()).shape == (2000, 12)
+
+
+# ---- against the REAL reference's simulate.py (fixture tests/golden/simulate_ref.npz, written by tests/golden/make_golden.py) --------
+def _ref():
+    import os
+
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "simulate_ref.npz"), allow_pickle=False))
+    return g
+
+
+def _same_distribution(a, b, what):
+    """Per-gene two-sample checks of integer samples a, b [cells][genes]: Kolmogorov-Smirnov (conservative on discrete data), means
+    within 4.5 pooled standard errors, variances within 30 %."""
+    from scipy import stats
+
+    G = a.shape[1]
+    for j in range(G):
+        x, y = a[:, j].astype(np.float64), b[:, j].astype(np.float64)
+        assert stats.ks_2samp(x, y).pvalue > 1e-4 / G * 10, (what, j, "KS")
+        se = np.sqrt(x.var() / len(x) + y.var() / len(y))
+        assert abs(x.mean() - y.mean()) <= 4.5 * se + 1e-9, (what, j, x.mean(), y.mean())
+        if x.var() > 0.05 and y.var() > 0.05:
+            assert 0.7 < x.var() / y.var() < 1.0 / 0.7, (what, j, x.var(), y.var())
+
+
+def test_extract_parameters_matches_the_reference():
+    """simulate.extract_parameters (reference simulate.py:13-33; deterministic) on the fixture's CSR: every output to 1e-9."""
+    import scipy.sparse as sp
+
+    from scrna_parameter_estimation_amd.memento import simulate
+
+    g = _ref()
+    X = sp.csr_matrix((g["in_data"].astype(np.float32), g["in_indices"], g["in_indptr"]), shape=tuple(g["in_shape"]))
+    (x_mean, x_var), (z_mean, z_var), Nc, good_idx = simulate.extract_parameters(X, q=float(g["q"]), min_mean=float(g["min_mean"]))
+    np.testing.assert_array_equal(good_idx, g["good_idx"])
+    for got, k in ((x_mean, "x_mean"), (x_var, "x_var"), (z_mean, "z_mean"), (z_var, "z_var"), (Nc, "Nc")):
+        np.testing.assert_allclose(got, g[k], rtol=1e-9, atol=1e-300, err_msg=k)
+
+
+def test_simulated_transcriptomes_are_distributed_like_the_references():
+    """simulate_transcriptomes -- independent negative binomials and the Gaussian copula with a given covariance (reference
+    simulate.py:52-89) -- against seeded samples of the real reference with the same parameters: per-gene marginals
+    (KS / mean / variance) and, for the copula, the Spearman correlation of neighbouring genes."""
+    from scipy import stats
+
+    from scrna_parameter_estimation_amd.memento import simulate
+
+    g = _ref()
+    n, means, variances, Nc = int(g["n_cells"]), g["sim_means"], g["sim_variances"], g["Nc"]
+    t = simulate.simulate_transcriptomes(n, means, variances, Nc, norm_cov="indep", seed=17)
+    _same_distribution(_dense(t.to_device_csr()), g["indep"], "indep")
+    np.random.seed(5)
+    tc = simulate.simulate_transcriptomes(n, means, variances, Nc, norm_cov=g["norm_cov"], seed=18)
+    mine, ref = _dense(tc.to_device_csr()), g["copula"]
+    _same_distribution(mine, ref, "copula")
+    np.testing.assert_allclose(mine.sum(axis=1).mean(), ref.sum(axis=1).mean(), rtol=0.02)        # cells rescaled to sizes drawn from Nc
+    for j in range(0, mine.shape[1] - 1, 3):
+        r_mine = stats.spearmanr(mine[:, j], mine[:, j + 1])[0]
+        r_ref = stats.spearmanr(ref[:, j], ref[:, j + 1])[0]
+        assert abs(r_mine - r_ref) < 0.07, (j, r_mine, r_ref)
+        far = stats.spearmanr(mine[:, j], mine[:, (j + 24) % mine.shape[1]])[0]
+        assert abs(far) < 0.12, (j, far)
+
+
+@pytest.mark.parametrize("process,key,q_sq", [("hyper", "cap_hyper", None), ("poisson", "cap_poisson", None), ("hyper", "cap_beta", 0.012)])
+def test_capture_sampling_is_distributed_like_the_references(process, key, q_sq):
+    """capture_sampling (reference simulate.py:91-115; hypergeometric, Poisson, Beta-distributed capture rates) of independent NB
+    transcriptomes against the real reference's captured counts from the same parameters: per-gene marginals and the per-cell
+    capture rates."""
+    from scipy import stats
+
+    from scrna_parameter_estimation_amd.memento import simulate
+
+    g = _ref()
+    n, means, variances, Nc = int(g["n_cells"]), g["sim_means"], g["sim_variances"], g["Nc"]
+    t = simulate.simulate_transcriptomes(n, means, variances, Nc, norm_cov="indep", seed=23)
+    np.random.seed(9)
+    qs, cap = simulate.capture_sampling(t, 0.1, q_sq=q_sq, process=process)
+    _same_distribution(_dense(cap), g[key], key)
+    ref_qs = g["qs_" + key.split("_")[1]]
+    if q_sq is None:
+        np.testing.assert_array_equal(qs, ref_qs)
+    else:
+        assert stats.ks_2samp(qs, ref_qs).pvalue > 1e-3 and abs(qs.mean() - ref_qs.mean()) < 0.003
