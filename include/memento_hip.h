@@ -222,7 +222,14 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
                      int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump,
                      int64_t co_resident_waves /* waves of mm_boot1d_chain launched beside this call (0 = none): with n_tiles they
                                                   decide between the two- and the three-waves-per-SIMD build of the kernel */,
-                     const mm_chain_tiles *chains /* NULL = every tile is a tile */, void *stream);
+                     const mm_chain_tiles *chains /* NULL = every tile is a tile */,
+                     const double *d_stream /* optional: the stream's uniforms from mm_pcg64_stream; every lane then reads its
+                                               uniforms from this table at its own position instead of stepping PCG64 */,
+                     int64_t stream_len, int32_t *d_stream_overflow /* set to 1 if a chain ran past the table: redo without it */,
+                     void *stream);
+/* d_out[i] = the (i + 1)-th uniform of Generator(PCG64(state)).random(): the ONE stream every chain of a launch replays
+ * (memento/bootstrap.py:102 seeds PCG64(5) per pair), produced once by lane-parallel jump-ahead. */
+int mm_pcg64_stream(const uint64_t pcg_state[4], int64_t n, double *d_out, void *stream);
 
 /* K6+K7 for LONG chains: one WAVE per (gene, group) chain instead of one lane.  A chain is one sequential PCG64 stream
  * (memento/bootstrap.py:102 re-seeds PCG64(5) per pair), so nothing but the generator itself parallelises: the 64 lanes
@@ -266,7 +273,10 @@ int mm_boot1d_fast(const double *d_pk, const double *d_lq, const double *d_v, co
  * d_n_invalid[row][2] = number of invalid (mean, res_var) replicates; a row with no valid entry is
  * reported as -1. */
 int mm_boot_fill_log(double *d_mean, double *d_var, int64_t n_rows, int64_t ld, int32_t num_boot, const double mv_fit[3],
-                     int32_t fill_mode, uint64_t fill_seed, int32_t *d_n_invalid, void *stream);
+                     int32_t fill_mode, uint64_t fill_seed, int32_t *d_n_invalid,
+                     const int64_t *d_row_key /* optional [n_rows]: the refill stream of a row is keyed by this instead of the row
+                                                 number, so that it is the same however the rows were chunked / sharded */,
+                     void *stream);
 
 /* ---- K9+K10: per-test linear contraction over groups and null statistics ------------------------
  * replaces hypothesis_test._regress_1d (linear part) and the counting part of _compute_asl

@@ -62,7 +62,8 @@ _SIGS = {
     "mm_bins_count": ([c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_bins_order": ([c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 13, ctypes.c_int),
     "mm_boot1d_replay": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
-                         c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
+                         c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "mm_pcg64_stream": ([ctypes.POINTER(c_uint64), c_int64, c_void_p, c_void_p], ctypes.c_int),
     "mm_boot1d_chain": ([c_void_p] * 6 + [c_int64, c_void_p, ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
                         c_void_p, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "mm_boot1d_async": ([c_void_p] * 6 + [c_int64, ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p,
@@ -71,7 +72,7 @@ _SIGS = {
     "mm_debug_replay_arith": ([c_int32], ctypes.c_int),
     "mm_boot1d_fast": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_boot_fill_log": ([c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_double), c_int32, c_uint64,
-                          c_void_p, c_void_p], ctypes.c_int),
+                          c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_contrast_stats": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                            c_void_p], ctypes.c_int),
     "mm_contrast_rows": ([c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p],

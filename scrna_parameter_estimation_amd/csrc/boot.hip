@@ -33,6 +33,57 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, int64_t ch, int 
                                            int32_t mean_only, int64_t ld, double *__restrict__ out_mean, double *__restrict__ out_var,
                                            int64_t *__restrict__ wave_clock);
 
+// Every chain of a launch replays the SAME stream: the reference seeds PCG64(5) anew for every (gene, group) pair
+// (memento/bootstrap.py:102).  So the stream's uniforms can be produced ONCE (k_pcg64_stream: lane-parallel jump-ahead, a few
+// milliseconds for millions of outputs) and a chain's generator shrinks to its position in that table: one gather load per
+// uniform instead of a 128-bit multiply-add, an xor-shift-rotate and an integer -> double conversion per lane (~45 VALU
+// instructions, ten of them quarter-rate multiplies: about a quarter of the tile kernel's VALU time).  Same uniforms, same draws.
+namespace npyrng {
+struct TableRng {
+  const double *__restrict__ tab;
+  int64_t len, pos;
+  int32_t *overflow;                 // set when a chain runs past the table (the host then redoes the launch with the arithmetic generator)
+  typedef int64_t Mark;
+  __device__ __forceinline__ Mark mark() const { return pos; }
+  __device__ __forceinline__ void rewind(Mark m) { pos = m; }
+  __device__ __forceinline__ void reserve(int) {}
+};
+__device__ __forceinline__ double pcg64_next_double(TableRng &g) {
+  int64_t p = g.pos++;
+  if (p >= g.len) {
+    *g.overflow = 1;
+    p = g.len - 1;
+  }
+  return g.tab[p];
+}
+template <bool TAB> struct GenOf { typedef Pcg64 type; };
+template <> struct GenOf<true> { typedef TableRng type; };
+}  // namespace npyrng
+
+// out[i] = the (i + 1)-th uniform of the stream that starts at ``state`` (numpy: Generator(PCG64).random()): every thread jumps
+// to the start of its run of 64 outputs (PCG's O(log n) advance) and steps through it.
+__global__ __launch_bounds__(256) void k_pcg64_stream(double *__restrict__ out, int64_t n, uint64_t st0, uint64_t st1, uint64_t st2,
+                                                      uint64_t st3) {
+  typedef unsigned __int128 u128;
+  const u128 MULT = ((u128)2549297995355413924ULL << 64) | 4865540595714422341ULL;
+  int64_t first = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 64;
+  if (first >= n) return;
+  u128 state = ((u128)st0 << 64) | st1, inc = ((u128)st2 << 64) | st3;
+  u128 acc_mult = 1, acc_plus = 0, cur_mult = MULT, cur_plus = inc;
+  for (uint64_t delta = (uint64_t)first; delta > 0; delta >>= 1) {
+    if (delta & 1) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+  }
+  state = acc_mult * state + acc_plus;
+  npyrng::Pcg64 g{(uint64_t)(state >> 64), (uint64_t)state, st2, st3};
+  int64_t last = first + 64 < n ? first + 64 : n;
+  for (int64_t i = first; i < last; i++) out[i] = npyrng::pcg64_next_double(g);
+}
+
 #ifndef BOOT_MIN_WAVES
 #define BOOT_MIN_WAVES 2
 #endif
@@ -41,7 +92,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, int64_t ch, int 
 #endif
 // MINW = waves per SIMD the register budget is set for: 2 when every tile is resident (<= 2048 tiles, the pairing order below
 // assumes two per SIMD), 3 in the many-tile regime where a third resident wave adds a little issue throughput.
-template <int MINW, bool FAST>
+template <int MINW, bool FAST, bool TAB>
 __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v, const double *__restrict__ a,
                                                        const double *__restrict__ b,
@@ -51,7 +102,9 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
                                                        uint64_t st2, uint64_t st3, int32_t num_boot, int32_t mean_only,
                                                        int64_t ld, double *__restrict__ out_mean, double *__restrict__ out_var,
                                                        int32_t *__restrict__ w_dump, int32_t kmax_dump,
-                                                       int64_t *__restrict__ wave_clock, ChainArgs ca) {
+                                                       int64_t *__restrict__ wave_clock, ChainArgs ca,
+                                                       const double *__restrict__ stream_tab, int64_t stream_len,
+                                                       int32_t *__restrict__ stream_overflow) {
   int lane = mm_lane();
   int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (tile >= n_tiles) return;
@@ -85,7 +138,18 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
       ov[r] = NAN;
     }
   }
-  npyrng::Pcg64 g{st0, st1, st2, st3};
+  typename npyrng::GenOf<TAB>::type g;
+  if constexpr (TAB) {
+    g.tab = stream_tab;
+    g.len = stream_len;
+    g.pos = 0;
+    g.overflow = stream_overflow;
+  } else {
+    g.s_hi = st0;
+    g.s_lo = st1;
+    g.i_hi = st2;
+    g.i_lo = st3;
+  }
   const bool run = K >= 2;
 #ifdef BOOT_STAMPS
   uint64_t stamp_inv = 0, stamp_btpe = 0, stamp_t0 = __builtin_amdgcn_s_memtime();
@@ -124,7 +188,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
                 X = xf >= 0 ? xf : npyrng::binomial_inversion_pre<int32_t>(g, dn, p, c_lq, U);
               }
               NPY_CLOCK(s1);
-              npyrng::Pcg64 saved = g;
+              auto saved = g.mark();
               bool bt = !zero && !inv;
               if (bt) {
                 NPY_CLOCK(stamp_bt[7]);
@@ -136,7 +200,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
               stamp_fastcall += s15 - s1;
               if (bt && X < 0) {
                 cnt_fb++;
-                g = saved;
+                g.rewind(saved);
                 X = npyrng::binomial_btpe<int32_t>(g, dn, p);
               }
               NPY_CLOCK(s2);
@@ -538,10 +602,14 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
 // Pass 3: log.
 __global__ __launch_bounds__(256) void k_boot_fill_log(double *__restrict__ mean, double *__restrict__ var, int64_t n_rows,
                                                        int64_t ld, int32_t num_boot, double f0, double f1, double f2,
-                                                       int32_t fill_mode, uint64_t seed, int32_t *__restrict__ n_invalid) {
+                                                       int32_t fill_mode, uint64_t seed, int32_t *__restrict__ n_invalid,
+                                                       const int64_t *__restrict__ row_key) {
   int lane = mm_lane();
   int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (row >= n_rows) return;
+  // the refill draws of a row are a function of (seed, key of the row, replicate): with the caller's keys (gene position in the
+  // unsharded gene order x groups + group) they do not depend on how the genes were chunked or sharded over GPUs
+  const uint64_t key = row_key ? (uint64_t)row_key[row] : (uint64_t)row;
   double *m = mean + row * ld + 1;
   double *s = var + row * ld + 1;
   int bad_m = 0, bad_v = 0;
@@ -581,7 +649,7 @@ __global__ __launch_bounds__(256) void k_boot_fill_log(double *__restrict__ mean
       for (int r = lane; r < num_boot; r += 64) {
         double cur = x[r];
         if (!(cur > 0.0) && !(cur < 0.0)) {  // NaN => invalid and not yet filled
-          uint64_t ctr = mix64(seed ^ mix64((uint64_t)row * 2 + which) ^ ((uint64_t)r << 20));
+          uint64_t ctr = mix64(seed ^ mix64(key * 2 + which) ^ ((uint64_t)r << 20));
           double pick = NAN;
           for (int attempt = 0; attempt < 4096; attempt++) {
             ctr = mix64(ctr + attempt);
@@ -770,7 +838,8 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
                      const int64_t *d_tile_ptr, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
                      const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot,
                      int32_t mean_only, int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump,
-                     int64_t co_resident_waves, const mm_chain_tiles *chains, void *stream) {
+                     int64_t co_resident_waves, const mm_chain_tiles *chains, const double *d_stream, int64_t stream_len,
+                     int32_t *d_stream_overflow, void *stream) {
   MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   ChainArgs ca{};
   if (chains) {
@@ -786,12 +855,26 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
   // (one tile per workgroup was measured too: worse when everything is resident, a wash in the many-tile regime)
   // the 168-VGPR build (three waves per SIMD) when this launch and the chain-kernel waves running beside it need more than two
   // wave slots per SIMD; the two-wave build otherwise
-  auto kern = n_tiles + (co_resident_waves > 0 ? co_resident_waves : 0) > 2048
-                  ? (g_exact_arith ? k_boot1d_replay<3, false> : k_boot1d_replay<3, true>)
-                  : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false> : k_boot1d_replay<BOOT_MIN_WAVES, true>);
+  MM_ARG(!d_stream || (stream_len > 0 && d_stream_overflow));
+  const bool three = n_tiles + (co_resident_waves > 0 ? co_resident_waves : 0) > 2048;
+  auto kern = d_stream ? (three ? (g_exact_arith ? k_boot1d_replay<3, false, true> : k_boot1d_replay<3, true, true>)
+                                : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false, true> : k_boot1d_replay<BOOT_MIN_WAVES, true, true>))
+                       : (three ? (g_exact_arith ? k_boot1d_replay<3, false, false> : k_boot1d_replay<3, true, false>)
+                                : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false, false> : k_boot1d_replay<BOOT_MIN_WAVES, true, false>));
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
-                     pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock, ca);
+                     pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock, ca, d_stream,
+                     stream_len, d_stream_overflow);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_pcg64_stream(const uint64_t pcg_state[4], int64_t n, double *d_out, void *stream) {
+  MM_ARG(pcg_state && d_out && n >= 0);
+  if (n == 0) return MM_OK;
+  int64_t threads = (n + 63) / 64;
+  hipLaunchKernelGGL(k_pcg64_stream, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_out, n, pcg_state[0],
+                     pcg_state[1], pcg_state[2], pcg_state[3]);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -827,13 +910,13 @@ int mm_boot1d_async(const double *d_ops, const int64_t *d_ch_base, const int32_t
 }
 
 int mm_boot_fill_log(double *d_mean, double *d_var, int64_t n_rows, int64_t ld, int32_t num_boot, const double mv_fit[3],
-                     int32_t fill_mode, uint64_t fill_seed, int32_t *d_n_invalid, void *stream) {
+                     int32_t fill_mode, uint64_t fill_seed, int32_t *d_n_invalid, const int64_t *d_row_key, void *stream) {
   MM_ARG(d_mean && d_var && mv_fit && d_n_invalid && n_rows >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   MM_ARG(fill_mode == 0 || fill_mode == 1);
   if (n_rows == 0) return MM_OK;
   int64_t blocks = (n_rows + 3) / 4;
   hipLaunchKernelGGL(k_boot_fill_log, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_mean, d_var, n_rows, ld, num_boot,
-                     mv_fit[0], mv_fit[1], mv_fit[2], fill_mode, fill_seed, d_n_invalid);
+                     mv_fit[0], mv_fit[1], mv_fit[2], fill_mode, fill_seed, d_n_invalid, d_row_key);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -501,6 +501,27 @@ def pcg64_jump_table(seed=5):
     return _JUMP_CACHE[seed]
 
 
+_STREAM_CACHE = {}
+STREAM_TABLE = __import__('os').environ.get('MM_STREAM_TABLE', '0') != '0'     # tile kernel: uniforms from the precomputed stream table;
+                            # OFF: measured slower (C3: 4.12-4.16 s against 3.53 s -- a wave's lanes sit at 64 different places of the
+                            # table, and the gather's latency is exposed in every attempt; profiles/README.md)
+STREAM_PER_STEP = 3.0       # table length = this x (longest tile chain's steps) x replicates: a draw takes 1 (inversion) or 2 per
+                            # BTPE attempt (~2.4 on average) uniforms; a chain past the table flags the launch, which is redone
+
+
+def pcg64_stream_table(seed, n):
+    """Device table of the first ``n`` uniforms of Generator(PCG64(seed)) (mm_pcg64_stream); cached and grown on demand -- its
+    content depends on nothing but the seed."""
+    torch = _torch()
+    t = _STREAM_CACHE.get(seed)
+    if t is None or t.numel() < n:
+        n_alloc = int(n * 1.25) + 4096
+        t = empty((n_alloc,), torch.float64)
+        _lib.call("mm_pcg64_stream", pcg64_state(seed), n_alloc, P(t), _stream())
+        _STREAM_CACHE[seed] = t
+    return t
+
+
 def side_stream():
     """A second HIP stream (torch plumbing) on which the chain kernel runs beside the tile kernel."""
     if not _SIDE_STREAM:
@@ -617,11 +638,12 @@ class Bootstrap1D:
         self.yv[:, 0] = dev(np.asarray(true_rv_log, dtype=np.float64))
 
     def run(self, skip, r1, r0, mv_fit, fill_mode=0, fill_seed=0, dump_weights=False, pcg_seed=5, first_pair=0, target_waves=None,
-            fast=False, mean_only=False):
+            fast=False, mean_only=False, fill_keys=None):
         """Order bins, replay the bootstrap and fill/log for every pair >= ``first_pair`` that is not skipped.
 
         ``skip``[pair] bool; ``r1``/``r0``[pair] the two uniforms of bootstrap.py:62,65.  Rows below
-        ``first_pair`` are left untouched (used by the strict replay driver).  Returns n_invalid
+        ``first_pair`` are left untouched (used by the strict replay driver).  ``fill_keys`` [pair] int64: keys of the device
+        refill streams (fill_mode 0; default: the row number).  Returns n_invalid
         [n_pairs - first_pair][2] (host): invalid (mean, res_var) replicates per row, -1 = no valid one."""
         torch = _torch()
         s = _stream()
@@ -755,11 +777,21 @@ class Bootstrap1D:
             _lib.call("mm_boot1d_fast", *[P(o) for o in ops], P(d_tile_ptr), n_tiles * 64, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       int(fill_seed) & ((1 << 64) - 1), B, int(mean_only), ld, P(self.ym), P(self.yv), s)
         elif n_tiles:
+            d_tab, tab_len, tab_over = None, 0, None
+            if STREAM_TABLE and int(tile_k.max()) > 1:
+                tab_len = int(STREAM_PER_STEP * (int(tile_k.max()) - 1) * B) + 4096
+                d_tab = pcg64_stream_table(pcg_seed, tab_len)
+                tab_over = zeros((1,), torch.int32)
             _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, n_launch,
-                      ctypes.byref(chain_tiles) if chain_tiles is not None else None, s)
+                      ctypes.byref(chain_tiles) if chain_tiles is not None else None, P(d_tab), tab_len, P(tab_over), s)
         if n_launch:
             torch.cuda.current_stream().wait_stream(side)
+        if n_tiles and not fast and tab_over is not None and int(tab_over.item()):
+            # a chain consumed more uniforms than the table holds (never seen): the tile launch again with the arithmetic generator
+            _lib.call("mm_boot1d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
+                      pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump, n_launch,
+                      ctypes.byref(chain_tiles) if chain_tiles is not None else None, None, 0, None, s)
         st = int(status.item())
         if st & 2 or st & 4:
             raise RuntimeError(f"mm_bins_order inconsistency (status {st})")
@@ -771,8 +803,9 @@ class Bootstrap1D:
         n_inv = empty((max(1, n_rows), 2), torch.int32)
         fit = (ctypes.c_double * 3)(*[float(x) for x in mv_fit])
         if n_rows > 0:
+            d_keys = dev(np.asarray(fill_keys, dtype=np.int64)[first_pair:]) if fill_keys is not None else None
             _lib.call("mm_boot_fill_log", c_void_p(self.ym.data_ptr() + first_pair * ld * 8), c_void_p(self.yv.data_ptr() + first_pair * ld * 8),
-                      n_rows, ld, B, fit, int(fill_mode), int(fill_seed) & ((1 << 64) - 1), P(n_inv), s)
+                      n_rows, ld, B, fit, int(fill_mode), int(fill_seed) & ((1 << 64) - 1), P(n_inv), P(d_keys), s)
         self.active = active
         return host(n_inv)[:n_rows]
 

@@ -509,7 +509,9 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
                 r1[:], r0[:] = shard_stream[0][g0 * ng:g1 * ng], shard_stream[1][g0 * ng:g1 * ng]
             else:
                 draw_stream(0)
-            n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only)   # K6-K8
+            keys = (fill_pos[g0:g1, None] * ng + np.arange(ng)[None, :]).reshape(-1)      # refill streams keyed by (gene, group)
+            n_inv = bs.run(skip, r1, r0, fit, fill_mode=0, fill_seed=fill_seed, fast=(rng == 'fast'), mean_only=mean_only,
+                           fill_keys=keys)                                                # K6-K8
             bad_fill = (n_inv < 0).any(axis=1)
             # how much of the result depends on the device refill (strict=True replays the reference's own _fill draws instead):
             # chains / genes with at least one refilled replicate -- all others are bit-identical to the strict path
@@ -663,23 +665,42 @@ def ht_1d_moments(adata, covariate, treatment, treatment_for_gene=None, inplace=
         # two hash uniforms per live (gene, group) chain, gene-major.  A rank must therefore use the uniforms at the positions its
         # genes have in the UNSHARDED order: gather (position, live chains) of every kept gene, draw the whole stream (the same
         # on every rank: the caller seeds all ranks alike) and keep this rank's entries.  N-rank results then equal 1-rank results.
-        if strict:
-            raise NotImplementedError("strict=True replays the reference's _fill draws, which shift the global stream gene after "
-                                      "gene: it is sequential over all genes -- run it on one rank")
         shard = getattr(st, 'shard', None)
         if shard is not None:
             gene_pos = np.asarray(shard, dtype=np.int64)[st.gene_idx]
         else:                               # the caller pre-sliced X: contiguous blocks in rank order
             sizes = comm.allgather_objects(int(st.csr.shape[1]))
             gene_pos = int(sum(sizes[:comm.rank])) + np.asarray(st.gene_idx, dtype=np.int64)
-        from ..dist import shard_stream_uniforms
-        shard_stream = shard_stream_uniforms(comm, gene_pos, (~_pair_skip(true_mean, true_rv)).reshape(G_all, ng))
+        if strict:
+            # strict=True also replays the reference's _fill draws, which shift the global stream gene after gene: sequential over
+            # ALL genes.  With contiguous shards the ranks take turns in rank order and hand the stream state on (the validation
+            # mode: exact, no speed-up); interleaved (cost-balanced) shards cannot be replayed that way.
+            spans = comm.allgather_objects((int(gene_pos.min()), int(gene_pos.max())) if len(gene_pos) else None)
+            spans = [sp_ for sp_ in spans if sp_ is not None]
+            if any(a[1] >= b[0] for a, b in zip(spans[:-1], spans[1:])):
+                raise NotImplementedError("strict=True over several ranks needs contiguous gene shards in rank order "
+                                          "(setup_memento(shard='contiguous') or a pre-sliced range); cost-balanced shards interleave")
+        else:
+            from ..dist import shard_stream_uniforms
+            shard_stream = shard_stream_uniforms(comm, gene_pos, (~_pair_skip(true_mean, true_rv)).reshape(G_all, ng))
+    # position of every kept gene in the unsharded, unfiltered gene order: keys the device refill streams, so that the timed mode's
+    # results do not depend on gene chunking or on the sharding over GPUs
+    fill_pos = (np.asarray(st.shard, dtype=np.int64)[st.gene_idx] if getattr(st, 'shard', None) is not None
+                else (gene_pos if gene_pos is not None else np.asarray(st.gene_idx, dtype=np.int64)))
     st.refill_stats = dict(chains=0, chains_refilled=0, genes=0, genes_refilled=0, gene_refilled=np.zeros(G_all, dtype=bool))
     st.last_bootstrap = None                   # the previous call's replicate rows (GBs) go back to the caching allocator BEFORE this call allocates its own
     if max_rows is None:                       # replicate buffers sized to the free HBM (288 GB on MI355X)
         max_rows = engine.auto_max_rows(num_boot + 1, arrays=2)
     chunk = G_all if strict else max(1, int(max_rows) // max(1, ng))   # strict replay is sequential over all genes
-    parts = [run_range(g0, min(G_all, g0 + chunk)) for g0 in range(0, G_all, chunk)] if G_all else []
+    if sharded and strict:
+        parts = []
+        for turn in range(comm.world):                # rank after rank, the np.random state handed on
+            if turn == comm.rank:
+                parts = [run_range(g0, min(G_all, g0 + chunk)) for g0 in range(0, G_all, chunk)] if G_all else []
+            states = comm.allgather_objects(np.random.get_state() if turn == comm.rank else None)
+            np.random.set_state(states[turn])
+    else:
+        parts = [run_range(g0, min(G_all, g0 + chunk)) for g0 in range(0, G_all, chunk)] if G_all else []
     keys = ('mean_coef', 'mean_se', 'mean_asl', 'var_coef', 'var_se', 'var_asl')
     out = {k: (np.concatenate([p_[k] for p_ in parts]) if parts else np.zeros(0)) for k in keys}
     m['1d_ht'] = {}

@@ -235,3 +235,13 @@ def test_fill_log_and_contract(eng, orc, api_small):
             ok = np.all(np.isfinite(ym[rows]), axis=0) & np.all(np.isfinite(yv[rows]), axis=0)
             assert stats[i, 2] == ok[1:].sum()
             assert np.array_equal(np.isnan(coef[i]), ~ok)
+
+
+def test_pcg64_stream_table_equals_numpy(eng):
+    """mm_pcg64_stream (lane-parallel jump-ahead): the table every lane of the tile kernel reads its uniforms from is numpy's
+    Generator(PCG64(5)).random() stream, double for double -- also across the 64-output runs of the generating threads."""
+    n = 300_001
+    t = eng.pcg64_stream_table(5, n)
+    np.testing.assert_array_equal(eng.host(t)[:n], np.random.Generator(np.random.PCG64(5)).random(n))
+    t7 = eng.pcg64_stream_table(7, 1000)
+    np.testing.assert_array_equal(eng.host(t7)[:1000], np.random.Generator(np.random.PCG64(7)).random(1000))

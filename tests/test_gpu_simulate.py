@@ -246,8 +246,9 @@ def test_simulated_transcriptomes_are_distributed_like_the_references():
         r_mine = stats.spearmanr(mine[:, j], mine[:, j + 1])[0]
         r_ref = stats.spearmanr(ref[:, j], ref[:, j + 1])[0]
         assert abs(r_mine - r_ref) < 0.07, (j, r_mine, r_ref)
-        far = stats.spearmanr(mine[:, j], mine[:, (j + 24) % mine.shape[1]])[0]
-        assert abs(far) < 0.12, (j, far)
+        k = (j + 24) % mine.shape[1]          # far apart in the copula (0.7^24): what is left is the shared cell size
+        far, far_ref = stats.spearmanr(mine[:, j], mine[:, k])[0], stats.spearmanr(ref[:, j], ref[:, k])[0]
+        assert abs(far - far_ref) < 0.07 and abs(far) < 0.25, (j, far, far_ref)
 
 
 @pytest.mark.parametrize("process,key,q_sq", [("hyper", "cap_hyper", None), ("poisson", "cap_poisson", None), ("hyper", "cap_beta", 0.012)])
