@@ -46,7 +46,7 @@ CONFIGS = {
     "C5s": dict(cells=60_000, genes=3_000, density=0.05, n_cond=101, n_rep=1, num_boot=500),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-TRAFFIC_FILE = "r02_k1_traffic_C3.json"   # this round's PMC record of K1's HBM traffic (tools/k1_traffic.py)
+TRAFFIC_FILE = "r03_k1_traffic_C3.json"   # this round's PMC record of K1's HBM traffic (tools/k1_traffic.py)
 
 
 def calibrated_profile(cfg, seed):

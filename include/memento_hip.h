@@ -191,6 +191,13 @@ int mm_debug_wave_clock(int64_t *d_buf);
  * arithmetic; 0 (default) uses the guarded fp32 evaluation of those loops (csrc/npy_rng.h: same integer draws, the guard sends
  * the ~0.1-0.5 % of draws that land near a decision threshold to the fp64 arithmetic).  Process-wide switch. */
 int mm_debug_replay_arith(int32_t exact);
+/* Measurement / test aid: on != 0 (default) lets every lane of mm_boot1d_replay produce its PCG64 uniforms AHEAD of their use, all
+ * lanes together a fixed number of times per bin step, into a 16-slot ring in LDS (the draws read them back); 0 = every sampler
+ * call site steps the generator for the lanes that draw there (rounds 1-2).  Same stream, same draws.  Process-wide switch. */
+int mm_debug_replay_ring(int32_t on);
+/* Timing experiments only -- WRONG results: rows > 0 makes every tile of mm_boot1d_replay read its operand rows modulo ``rows``
+ * (a cache-resident region), which separates the kernel's arithmetic from its operand traffic.  0 (default) = off. */
+int mm_debug_replay_rows_mod(int64_t rows);
 
 /* ---- K6+K7: replay bootstrap -- numpy Generator(PCG64).multinomial draw-for-draw + replicate moments
  * replaces bootstrap._bootstrap_1d  memento/bootstrap.py:97-110 and the tuple branch of

@@ -70,6 +70,8 @@ _SIGS = {
                         c_int32, c_void_p], ctypes.c_int),
     "mm_debug_wave_clock": ([c_void_p], ctypes.c_int),
     "mm_debug_replay_arith": ([c_int32], ctypes.c_int),
+    "mm_debug_replay_ring": ([c_int32], ctypes.c_int),
+    "mm_debug_replay_rows_mod": ([c_int64], ctypes.c_int),
     "mm_boot1d_fast": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_boot_fill_log": ([c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_double), c_int32, c_uint64,
                           c_void_p, c_void_p, c_void_p], ctypes.c_int),

@@ -27,6 +27,7 @@ struct ChainArgs {
   const int32_t *tile_chain;   // [tile] chain index or -1 (tile kernel only; may be NULL)
   int32_t *w_dump;             // optional weights [chain][k][b]
   int32_t kmax_dump;
+  int64_t debug_rows_mod;      // timing experiments only (mm_debug_replay_rows_mod): > 0 = tiles read operand rows modulo this (WRONG results)
 };
 template <bool FAST>
 __device__ __forceinline__ void chain_body(const ChainArgs &ca, int64_t ch, int lane, uint64_t st0, uint64_t st1, int32_t num_boot,
@@ -47,6 +48,7 @@ struct TableRng {
   __device__ __forceinline__ Mark mark() const { return pos; }
   __device__ __forceinline__ void rewind(Mark m) { pos = m; }
   __device__ __forceinline__ void reserve(int) {}
+  __device__ __forceinline__ int max_attempts() const { return 16; }
 };
 __device__ __forceinline__ double pcg64_next_double(TableRng &g) {
   int64_t p = g.pos++;
@@ -56,8 +58,53 @@ __device__ __forceinline__ double pcg64_next_double(TableRng &g) {
   }
   return g.tab[p];
 }
-template <bool TAB> struct GenOf { typedef Pcg64 type; };
-template <> struct GenOf<true> { typedef TableRng type; };
+// RING generator: the lane's own PCG64 stream, produced AHEAD of its use into a 16-slot ring in LDS.  In the lock-step tile
+// kernel every sampler call site costs the whole wave a PCG64 step (~45 VALU instructions, a third of them quarter-rate
+// multiplies) however few lanes draw there: seven sites per bin step (one for the inversion sampler, two per BTPE attempt of the
+// unluckiest lane) for ~1.5 uniforms a lane actually uses.  With the ring ALL lanes step their generators together, a fixed
+// number of times per bin step (top_up), and a draw just reads its uniforms back (ds_read); a lane that runs dry mid-draw steps
+// its generator on the spot.  Same stream, same uniforms in the same order.  Rewinding (the exact redo of a guarded draw) moves
+// the read position back: the ring keeps the last 16 uniforms, so the fast BTPE may use 14 (7 attempts) before it must hand over.
+struct RingRng {
+  uint64_t s_hi, s_lo, i_hi, i_lo;   // generator state at stream position ``tail``
+  int32_t head, tail;                // uniforms consumed / produced so far (slot = position & 15)
+  double *ring;                      // this lane's column of the [16][256] LDS ring (stride 256 doubles)
+  typedef int32_t Mark;
+  __device__ __forceinline__ Mark mark() const { return head; }
+  __device__ __forceinline__ void rewind(Mark m) { head = m; }
+  __device__ __forceinline__ void reserve(int) {}
+  __device__ __forceinline__ int max_attempts() const { return 7; }
+  __device__ __forceinline__ double step() {
+    Pcg64 g{s_hi, s_lo, i_hi, i_lo};
+    double u = pcg64_next_double(g);
+    s_hi = g.s_hi;
+    s_lo = g.s_lo;
+    return u;
+  }
+  __device__ __forceinline__ void top_up(int rounds) {      // every lane with room produces ``rounds`` more uniforms (wave-uniform trip count)
+    for (int j = 0; j < rounds; j++) {
+      if (tail - head < 16) {
+        ring[(tail & 15) * 256] = step();
+        tail++;
+      }
+    }
+  }
+};
+__device__ __forceinline__ double pcg64_next_double(RingRng &g) {
+  double u;
+  if (g.head == g.tail) {            // ring empty: produce on the spot (and keep it, a rewind may come back to it)
+    u = g.step();
+    g.ring[(g.tail & 15) * 256] = u;
+    g.tail++;
+  } else {
+    u = g.ring[(g.head & 15) * 256];
+  }
+  g.head++;
+  return u;
+}
+template <int MODE> struct GenOf { typedef Pcg64 type; };     // MODE 0: arithmetic, 1: stream table, 2: ring
+template <> struct GenOf<1> { typedef TableRng type; };
+template <> struct GenOf<2> { typedef RingRng type; };
 }  // namespace npyrng
 
 // out[i] = the (i + 1)-th uniform of the stream that starts at ``state`` (numpy: Generator(PCG64).random()): every thread jumps
@@ -92,7 +139,10 @@ __global__ __launch_bounds__(256) void k_pcg64_stream(double *__restrict__ out, 
 #endif
 // MINW = waves per SIMD the register budget is set for: 2 when every tile is resident (<= 2048 tiles, the pairing order below
 // assumes two per SIMD), 3 in the many-tile regime where a third resident wave adds a little issue throughput.
-template <int MINW, bool FAST, bool TAB>
+#ifndef BOOT_RING_ROUNDS
+#define BOOT_RING_ROUNDS 2       // uniforms every lane produces ahead per bin step in ring mode (a lane uses ~1.5 on average)
+#endif
+template <int MINW, bool FAST, int TAB>
 __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v, const double *__restrict__ a,
                                                        const double *__restrict__ b,
@@ -127,6 +177,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
   if (K <= 0 || row < 0) K = 0;  // unused lane
   int64_t row0 = tile_ptr[tile];
   int kmax = (int)(tile_ptr[tile + 1] - row0);
+  if (ca.debug_rows_mod > 0) row0 %= ca.debug_rows_mod;     // (timing experiment: operands out of a cache-resident region)
   double nobs = slot_nobs[slot];
   double omq = slot_omq[slot];  // 1 - q of the pair's group
   int32_t n = (int32_t)nobs;  // N_g < 2^31 (checked by the host)
@@ -139,7 +190,17 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
     }
   }
   typename npyrng::GenOf<TAB>::type g;
-  if constexpr (TAB) {
+  if constexpr (TAB == 2) {
+    __shared__ double ring_lds[16 * 256];
+    g.s_hi = st0;
+    g.s_lo = st1;
+    g.i_hi = st2;
+    g.i_lo = st3;
+    g.head = 0;
+    g.tail = 0;
+    g.ring = ring_lds + threadIdx.x;
+    g.top_up(10);
+  } else if constexpr (TAB == 1) {
     g.tab = stream_tab;
     g.len = stream_len;
     g.pos = 0;
@@ -169,6 +230,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
       int kn = k + 1 < kmax ? k + 1 : 0;
       int64_t on = obase + (int64_t)kn * 64;
       double n_pk = pk_[on], n_lq = lq_[on], n_v = v[on], n_a = a[on], n_b = b[on];
+      if constexpr (TAB == 2) g.top_up(BOOT_RING_ROUNDS);
       if (run && k < K) {
         int32_t w;
         if (k < K - 1) {
@@ -312,6 +374,7 @@ struct WaveRng {
   __device__ __forceinline__ void reserve(int n) {
     if (pos > 64 - n) refill();
   }
+  __device__ __forceinline__ int max_attempts() const { return 16; }
 };
 
 __device__ __forceinline__ double pcg64_next_double(WaveRng &g) {
@@ -484,8 +547,7 @@ __global__ __launch_bounds__(256, ASYNC_MIN_WAVES) void k_boot1d_async(const dou
   double *om = out_mean + row * ld + 1;
   double *ov = out_var + row * ld + 1;
   Pcg64 g{st0, st1, st2, st3};
-  LaneDraw D;
-  D.w = 0;
+  LaneDraw D = LaneDraw();
   int32_t state = K ? LS_RESTART : LS_IDLE;
   int32_t r = 0, k = 0, dn = n;
   double M1 = 0.0, M2 = 0.0;
@@ -550,18 +612,19 @@ __global__ __launch_bounds__(256, ASYNC_MIN_WAVES) void k_boot1d_async(const dou
     }
     ASYNC_STAMP(0);
     // ---- the draw of bin k, phase by phase (csrc/npy_rng.h) ------------------------------------------------------------------
-    if (state == LS_START) {
-      if (FAST) {
-        state = lane_begin(D, g, cur.pk, cur.lq, dn);
-      } else {                                                   // mm_debug_replay_arith(1): numpy's arithmetic, draw by draw
-        D.w = binomial_pre<int32_t, false>(g, cur.pk, cur.lq, dn);
-        state = LS_DONE;
-      }
+    if (FAST) {
+      // start + inversion segment + BTPE attempt in one straight line for every lane (csrc/npy_rng.h: the branch-free forms):
+      // the independent dependency chains interleave instead of queueing behind three branches
+      int32_t s0 = lane_begin_bf(D, g, cur.pk, cur.lq, dn > 0 ? dn : 1, state == LS_START);
+      state = state == LS_START ? s0 : state;
+      ASYNC_STAMP(1);
+      state = lane_inv_att_bf(D, g, state);
+      ASYNC_STAMP(2);
+      if (state == LS_ATT2) state = lane_att_rest(D);
+    } else if (state == LS_START) {                              // mm_debug_replay_arith(1): numpy's arithmetic, draw by draw
+      D.w = binomial_pre<int32_t, false>(g, cur.pk, cur.lq, dn);
+      state = LS_DONE;
     }
-    ASYNC_STAMP(1);
-    if (state == LS_INV) state = lane_inv(D);
-    ASYNC_STAMP(2);
-    if (state == LS_ATT) state = lane_att(D, g);
     ASYNC_STAMP(3);
     if (state == LS_EXPL) state = lane_expl(D);
     ASYNC_STAMP(4);
@@ -820,12 +883,24 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
 }
 
 static int64_t *g_wave_clock = nullptr;  // set by mm_debug_wave_clock; nullptr = no profiling writes
+static int g_ring_rng = 0;               // set by mm_debug_replay_ring: 1 = the tile kernel's lanes produce their uniforms ahead into an LDS ring
+static int64_t g_debug_rows_mod = 0;    // MM_DEBUG_ROWS_MOD in the environment of the process (read once): timing experiments only
 static int g_exact_arith = 0;            // set by mm_debug_replay_arith: 1 = numpy's fp64 arithmetic in every search loop (A/B timing, tests)
 
 extern "C" {
 
 int mm_debug_wave_clock(int64_t *d_buf) {
   g_wave_clock = d_buf;
+  return MM_OK;
+}
+
+int mm_debug_replay_rows_mod(int64_t rows) {
+  g_debug_rows_mod = rows > 0 ? rows : 0;
+  return MM_OK;
+}
+
+int mm_debug_replay_ring(int32_t on) {
+  g_ring_rng = on ? 1 : 0;
   return MM_OK;
 }
 
@@ -842,11 +917,12 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
                      int32_t *d_stream_overflow, void *stream) {
   MM_ARG(d_pk && d_lq && d_v && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   ChainArgs ca{};
+  ca.debug_rows_mod = g_debug_rows_mod;
   if (chains) {
     MM_ARG(chains->d_tile_chain && chains->d_ops && chains->d_ch_base && chains->d_ch_K && chains->d_ch_nobs && chains->d_ch_omq &&
            chains->d_ch_row && chains->d_jump);
     ca = ChainArgs{chains->d_ops, chains->d_ch_base, chains->d_ch_K, chains->d_ch_nobs, chains->d_ch_omq, chains->d_ch_row, chains->d_jump,
-                   chains->d_tile_chain, chains->d_w_dump, chains->kmax_dump};
+                   chains->d_tile_chain, chains->d_w_dump, chains->kmax_dump, g_debug_rows_mod};
   }
   MM_ARG(d_out_mean && d_out_var && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
@@ -857,10 +933,13 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
   // wave slots per SIMD; the two-wave build otherwise
   MM_ARG(!d_stream || (stream_len > 0 && d_stream_overflow));
   const bool three = n_tiles + (co_resident_waves > 0 ? co_resident_waves : 0) > 2048;
-  auto kern = d_stream ? (three ? (g_exact_arith ? k_boot1d_replay<3, false, true> : k_boot1d_replay<3, true, true>)
-                                : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false, true> : k_boot1d_replay<BOOT_MIN_WAVES, true, true>))
-                       : (three ? (g_exact_arith ? k_boot1d_replay<3, false, false> : k_boot1d_replay<3, true, false>)
-                                : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false, false> : k_boot1d_replay<BOOT_MIN_WAVES, true, false>));
+  const int mode = d_stream ? 1 : (g_ring_rng ? 2 : 0);
+  auto kern = mode == 1 ? (three ? (g_exact_arith ? k_boot1d_replay<3, false, 1> : k_boot1d_replay<3, true, 1>)
+                                 : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false, 1> : k_boot1d_replay<BOOT_MIN_WAVES, true, 1>))
+            : mode == 2 ? (three ? (g_exact_arith ? k_boot1d_replay<3, false, 2> : k_boot1d_replay<3, true, 2>)
+                                 : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false, 2> : k_boot1d_replay<BOOT_MIN_WAVES, true, 2>))
+                        : (three ? (g_exact_arith ? k_boot1d_replay<3, false, 0> : k_boot1d_replay<3, true, 0>)
+                                 : (g_exact_arith ? k_boot1d_replay<BOOT_MIN_WAVES, false, 0> : k_boot1d_replay<BOOT_MIN_WAVES, true, 0>));
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock, ca, d_stream,
@@ -887,7 +966,7 @@ int mm_boot1d_chain(const double *d_ops, const int64_t *d_ch_base, const int32_t
   MM_ARG(n_chains >= 0 && n_chains < 2147483647LL && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_chains == 0) return MM_OK;
   auto kern = g_exact_arith ? k_boot1d_chain<false> : k_boot1d_chain<true>;
-  ChainArgs ca{d_ops, d_ch_base, d_ch_K, d_ch_nobs, d_ch_omq, d_ch_row, d_jump, nullptr, d_w_dump, kmax_dump};
+  ChainArgs ca{d_ops, d_ch_base, d_ch_K, d_ch_nobs, d_ch_omq, d_ch_row, d_jump, nullptr, d_w_dump, kmax_dump, 0};
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_chains + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ca, n_chains, pcg_state[0], pcg_state[1],
                      num_boot, mean_only, ld, d_out_mean, d_out_var, g_wave_clock ? g_wave_clock + MM_CHAIN_CLOCK_OFF : nullptr);
   MM_LAUNCH_CHECK();

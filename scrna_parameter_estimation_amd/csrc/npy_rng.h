@@ -70,6 +70,7 @@ struct Pcg64 {
   NPY_HDM Mark mark() const { return Mark{s_hi, s_lo}; }
   NPY_HDM void rewind(const Mark &m) { s_hi = m.hi; s_lo = m.lo; }
   NPY_HDM void reserve(int) {}
+  NPY_HDM int max_attempts() const { return 16; }   // attempts the guarded fast BTPE may make before it must be able to rewind
 };
 
 NPY_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
@@ -426,7 +427,8 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p
   const double p4 = p3 + c * rlamr;
   const double gu = 1e-11 * p4;                                       // set-up values are within ~1e-15 (relative) of numpy's
   NPY_ST(0);
-  for (int attempt = 0; attempt < 16; attempt++) {
+  const int max_att = g.max_attempts();
+  for (int attempt = 0; attempt < max_att; attempt++) {
     const bool tk = (Int)attempt <= n;   // always true (see NPY_KEEP)
     double u = pcg64_next_double(g) * p4;
     double v = pcg64_next_double(g);
@@ -521,7 +523,7 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p
 // can run a fixed sequence of phases per pass, each for the lanes that are in it, and let every lane move on to its next bin as
 // soon as ITS draw is done (csrc/boot.hip: k_boot1d_async).  The arithmetic, the guards and the fallback rule are those of
 // binomial_inversion_fast / binomial_btpe_fast above: the draw and the uniforms it consumes are numpy's in every case.
-enum LaneState : int32_t { LS_START = 0, LS_INV, LS_ATT, LS_EXPL, LS_SQZ, LS_XINV, LS_XBT, LS_DONE, LS_RESTART, LS_IDLE };
+enum LaneState : int32_t { LS_START = 0, LS_INV, LS_ATT, LS_ATT2, LS_EXPL, LS_SQZ, LS_XINV, LS_XBT, LS_DONE, LS_RESTART, LS_IDLE };
 
 struct LaneDraw {
   int32_t n;                 // cells left when the draw starts
@@ -536,7 +538,7 @@ struct LaneDraw {
   double p1, p2, p3, p4, xm, c, laml, lamr, nrq;
   int32_t m, attempts;
   uint64_t mk_hi, mk_lo;     // generator state at the start of the draw (the exact redo rewinds to it)
-  double v;                  // pending acceptance test: v and y of the current attempt
+  double u, v;               // the attempt in flight: its two uniforms (u scaled by p4), then v and y of the pending acceptance test
   int32_t y;
 };
 
@@ -819,6 +821,196 @@ NPY_HD int32_t lane_sqz(LaneDraw &D) {
   if (A > bound + gb) return LS_ATT;
   if (A < bound - gb) return lane_bt_accept(D, y);
   return LS_XBT;
+}
+
+// ---- the two common phases WITHOUT branches ------------------------------------------------------------------------------
+// A wave that runs alone on its SIMD issues a DEPENDENT instruction only every ~9 cycles but independent ones every 4: a pass
+// that runs "start", "inversion segment" and "BTPE attempt" one after the other, each behind its own branch, is latency-bound.
+// The forms below compute both samplers' next piece for EVERY lane in one straight line (values of lanes that are in another
+// state are computed on whatever their fields hold and dropped by selects), so that the compiler can interleave the two
+// dependency chains.  Same arithmetic as lane_begin / lane_inv / lane_att up to the order of two multiplications in the
+// inversion search (all segments now take 1/it from the reciprocal instruction); the guards and the exact redo are unchanged.
+NPY_HD float lane_inv_cap(int32_t n, float pf) {
+  // numpy restarts the search when X exceeds bound = min(n, np + 10 sqrt(npq + 1)) >= min(n, 10): stay strictly below it, below 60
+  // (longer searches go to the exact path), but never below min(n, 9), which cannot reach the bound
+  float nf = (float)n, qf = 1.0f - pf, npf = nf * pf;
+  float capf = npf + 10.0f * f_sqrt(npf * qf + 1.0f) - 1.5f;
+  float lo = nf < 9.0f ? nf : 9.0f;
+  capf = capf > lo ? capf : lo;
+  capf = capf < nf ? capf : nf;
+  return capf < 60.0f ? capf : 60.0f;
+}
+
+template <typename Gen>
+NPY_HD int32_t lane_begin_bf(LaneDraw &D, Gen &g, double pk, double lq, int32_t n, bool starting) {
+  const bool zero = pk == 0.0;
+  const bool flip = !(pk <= 0.5);
+  const double p = flip ? 1.0 - pk : pk;
+  const bool inv = p * (double)n <= 30.0;
+  // inversion set-up (the generator moves on only for lanes that start an inversion draw)
+  Gen g2 = g;
+  const double U = pcg64_next_double(g2);
+  const float nf = (float)n, pf = (float)p;
+  const float s_ = pf * f_rcp(1.0f - pf);
+  const float px0 = f_exp((float)((double)n * lq));
+  const int32_t cap = (int32_t)lane_inv_cap(n, pf);
+  // BTPE set-up, as in binomial_btpe_fast (for every lane; only the fallback of the fp32 square root is a branch)
+  const double r = p, q = 1.0 - r;
+  const double fm = (double)n * r + r;
+  const double md = floor(fm);
+  const double nrq = (double)n * r * q;
+  const float t = 2.195f * f_sqrt((float)nrq) - 4.6f * (float)q;
+  const float ft = floorf(t);
+  const float gt = 2e-6f * t + 1e-4f;
+  double p1 = (double)ft + 0.5;
+  if (starting && !zero && !inv && !(t - ft > gt && ft + 1.0f - t > gt)) p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+  const double xm = md + 0.5, xl = xm - p1, xr = xm + p1;
+  const double c = 0.134 + 20.5 * d_rcp(15.3 + md);
+  double a = (fm - xl) * d_rcp(fm - xl * r);
+  const double laml = a * (1.0 + a * 0.5);
+  a = (xr - fm) * d_rcp(xr * q);
+  const double lamr = a * (1.0 + a * 0.5);
+  const double p2 = p1 * (1.0 + 2.0 * c);
+  const double p3 = p2 + c * d_rcp(laml);
+  const double p4 = p3 + c * d_rcp(lamr);
+  if (!starting) return -1;
+  D.n = n;
+  D.flip = flip;
+  D.p = p;
+  if (zero) {
+    D.w = 0;
+    return LS_DONE;
+  }
+  if (inv) {
+    g = g2;
+    D.lq = lq;
+    D.U = U;
+    D.s = s_;
+    D.px = px0;
+    D.Uf = (float)U;
+    D.X = 0;
+    D.it = 1;
+    D.nf1 = nf + 1.0f;
+    D.cap = cap;
+    return LS_INV;
+  }
+  D.m = (int32_t)md;
+  D.nrq = nrq;
+  D.p1 = p1;
+  D.p2 = p2;
+  D.p3 = p3;
+  D.p4 = p4;
+  D.xm = xm;
+  D.c = c;
+  D.laml = laml;
+  D.lamr = lamr;
+  D.attempts = 0;
+  typename Gen::Mark mk = g.mark();
+  D.mk_hi = mk.hi;
+  D.mk_lo = mk.lo;
+  return LS_ATT;
+}
+
+// nine steps of the search for lanes in LS_INV, one attempt up to the triangular region for lanes in LS_ATT
+template <typename Gen>
+NPY_HD int32_t lane_inv_att_bf(LaneDraw &D, Gen &g, int32_t state) {
+  const bool inI = state == LS_INV, inA = state == LS_ATT;
+  // ---- inversion segment
+  float Uf = D.Uf, px = D.px;
+  const float s = D.s, nf1 = D.nf1;
+  int32_t X = D.X, it = D.it;
+  const int32_t cap = D.cap;
+  float f[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    float itf = (float)(D.it + j);
+    f[j] = ((nf1 - itf) * s) * f_rcp(itf);
+  }
+  bool stopped = false;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    stopped = stopped || !(Uf > px) || it > cap || it > 60;
+    float Un = Uf - px, pn = px * f[j];
+    X = stopped ? X : it;
+    Uf = stopped ? Uf : Un;
+    px = stopped ? px : pn;
+    it = stopped ? it : it + 1;
+  }
+  const bool okI = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);      // false when the search stopped at a cap
+  const int32_t sI = !stopped ? (int32_t)LS_INV : (okI ? (int32_t)LS_DONE : (int32_t)LS_XINV);
+  // ---- BTPE attempt: two uniforms, region, the triangular region's candidate
+  Gen g2 = g;
+  const double p1 = D.p1, p2 = D.p2, p3 = D.p3, p4 = D.p4, xm = D.xm;
+  const double gu = 1e-11 * p4;
+  const double u = pcg64_next_double(g2) * p4;
+  const double v = pcg64_next_double(g2);
+  const bool near = fabs(u - p1) < gu || fabs(u - p2) < gu || fabs(u - p3) < gu;
+  const bool tri = u <= p1;
+  const double x = xm - p1 * v + u;
+  const double fx = floor(x);
+  const double gx = 1e-10 * (fabs(x) + 1.0);
+  const bool bad = (x - fx < gx || fx + 1.0 - x < gx) || fx < 0.0 || fx > (double)D.n;
+  const bool tired = D.attempts >= 16;
+  const int32_t sA = (tired || near) ? (int32_t)LS_XBT : (tri ? (bad ? (int32_t)LS_XBT : (int32_t)LS_DONE) : (int32_t)LS_ATT2);
+  const int32_t yA = (tri && !bad) ? (int32_t)fx : 0;
+  // ---- commit
+  if (inI) {
+    D.Uf = Uf;
+    D.px = px;
+    D.X = X;
+    D.it = it;
+    if (sI == LS_DONE) D.w = D.flip ? D.n - X : X;
+    return sI;
+  }
+  if (inA) {
+    if (!tired) {
+      g = g2;
+      D.attempts++;
+      D.u = u;
+      D.v = v;
+    }
+    if (sA == LS_DONE) D.w = D.flip ? D.n - yA : yA;
+    return sA;
+  }
+  return state;
+}
+
+// Phase ATT2: the attempt's candidate outside the triangular region (parallelogram / exponential tails) -> the acceptance test it
+// needs (LS_EXPL / LS_SQZ), a rejection (LS_ATT), or LS_XBT.
+NPY_HD int32_t lane_att_rest(LaneDraw &D) {
+  const double p1 = D.p1, p2 = D.p2, p3 = D.p3, xm = D.xm, u = D.u;
+  double v = D.v;
+  const int32_t n = D.n, m = D.m;
+  const double xl = xm - p1, xr = xm + p1;
+  double x, gx;
+  if (u <= p2) {                       // parallelogram
+    const double c = D.c;
+    x = xl + (u - p1) * d_rcp(c);
+    v = v * c + 1.0 - fabs((double)m - x + 0.5) * d_rcp(p1);
+    if (fabs(v - 1.0) < 1e-10) return LS_XBT;
+    if (v > 1.0) return LS_ATT;
+    gx = 1e-10 * (fabs(x) + 1.0);
+  } else {                             // exponential tails: fp32 logarithm
+    if (v == 0.0) return LS_ATT;
+    float lv = f_log((float)v);
+    bool left = u <= p3;
+    double lam = left ? D.laml : D.lamr;
+    double rl = d_rcp(lam);
+    x = left ? xl + (double)lv * rl : xr - (double)lv * rl;
+    gx = (2e-6 * fabs((double)lv) + 4e-7) * rl + 1e-10 * (fabs(x) + 1.0);
+    v = left ? v * (u - p2) * lam : v * (u - p3) * lam;
+  }
+  double fx = floor(x);
+  if (x - fx < gx || fx + 1.0 - x < gx) return LS_XBT;
+  if (fx < 0.0 || fx > (double)n) {
+    if (u <= p2) return LS_XBT;        // cannot happen inside the two central regions; be safe
+    return LS_ATT;                     // numpy: y < 0 (left tail) / y > n (right tail)
+  }
+  int32_t y = (int32_t)fx;
+  int32_t k = y > m ? y - m : m - y;
+  D.v = v;
+  D.y = y;
+  return (!((k > 20) && ((double)k < D.nrq / 2.0 - 1))) ? LS_EXPL : LS_SQZ;
 }
 
 // Phase XBT: rewind the generator to the start of the draw and run numpy's BTPE.

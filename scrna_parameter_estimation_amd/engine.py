@@ -501,6 +501,8 @@ def pcg64_jump_table(seed=5):
     return _JUMP_CACHE[seed]
 
 
+REPLAY_RING = __import__('os').environ.get('MM_REPLAY_RING', '0') != '0'       # tile kernel: uniforms produced ahead into an LDS ring (mm_debug_replay_ring);
+                            # OFF: measured slower at every top-up rate (C3: 3.61 / 3.71 / 3.80 s with 2 / 3 / 4 per step against 3.53 s)
 _STREAM_CACHE = {}
 STREAM_TABLE = __import__('os').environ.get('MM_STREAM_TABLE', '0') != '0'     # tile kernel: uniforms from the precomputed stream table;
                             # OFF: measured slower (C3: 4.12-4.16 s against 3.53 s -- a wave's lanes sit at 64 different places of the
@@ -777,6 +779,8 @@ class Bootstrap1D:
             _lib.call("mm_boot1d_fast", *[P(o) for o in ops], P(d_tile_ptr), n_tiles * 64, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       int(fill_seed) & ((1 << 64) - 1), B, int(mean_only), ld, P(self.ym), P(self.yv), s)
         elif n_tiles:
+            _lib.call("mm_debug_replay_ring", 1 if REPLAY_RING else 0)
+            _lib.call("mm_debug_replay_rows_mod", int(__import__('os').environ.get('MM_DEBUG_ROWS_MOD', '0')))      # timing experiments only
             d_tab, tab_len, tab_over = None, 0, None
             if STREAM_TABLE and int(tile_k.max()) > 1:
                 tab_len = int(STREAM_PER_STEP * (int(tile_k.max()) - 1) * B) + 4096

@@ -122,6 +122,48 @@ void host_multinomial_async(const uint64_t st[4], int64_t n, const double *pix, 
   delete[] lq;
 }
 
+// ... and through the branch-free forms of the two common phases (lane_begin_bf / lane_inv_att_bf / lane_att_rest), called the way
+// k_boot1d_async calls them: for every pass, whatever the lane's state
+void host_multinomial_async_bf(const uint64_t st[4], int64_t n, const double *pix, int d, int B, int64_t *out) {
+  using namespace npyrng;
+  Pcg64 g{st[0], st[1], st[2], st[3]};
+  double *pk = new double[d], *lq = new double[d];
+  double rem = 1.0;
+  for (int j = 0; j < d - 1; j++) {
+    pk[j] = pix[j] / rem;
+    lq[j] = binomial_lq(pk[j]);
+    rem -= pix[j];
+  }
+  LaneDraw D = LaneDraw();
+  for (int b = 0; b < B; b++) {
+    int64_t *mn = out + (int64_t)b * d;
+    int32_t dn = (int32_t)n;
+    int k = 0;
+    int32_t state = LS_START;
+    long pass = 0;
+    while (k < d - 1 && dn > 0) {
+      pass++;
+      int32_t s0 = lane_begin_bf(D, g, pk[k], lq[k], dn > 0 ? dn : 1, state == LS_START);
+      if (state == LS_START) state = s0;
+      state = lane_inv_att_bf(D, g, state);
+      if (state == LS_ATT2) state = lane_att_rest(D);
+      if (state == LS_EXPL) state = lane_expl(D);
+      if ((pass & 1) == 0 && state == LS_SQZ) state = lane_sqz(D);
+      if ((pass & 7) == 0 && state == LS_XINV) state = lane_xinv(D, g);
+      if ((pass & 7) == 0 && state == LS_XBT) state = lane_xbt(D, g);
+      if (state == LS_DONE) {
+        mn[k] = D.w;
+        dn -= D.w;
+        k++;
+        state = LS_START;
+      }
+    }
+    if (dn > 0) mn[d - 1] = dn;
+  }
+  delete[] pk;
+  delete[] lq;
+}
+
 // count binomial draws through binomial_pre<.., true> with explicit (n, p) and return the two fallback counters
 void host_binomial_fast(const uint64_t st[4], double p, int64_t n, int count, int64_t *out) {
   npyrng::Pcg64 g{st[0], st[1], st[2], st[3]};

@@ -84,7 +84,7 @@ def test_multinomial_random_shapes(shim):
         pv = mult / mult.sum()
         B = 50
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
-        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async", "host_multinomial_async_bf"):
             got = _multi(shim, 5, n, pv, B, fn)
             np.testing.assert_array_equal(got, ref, err_msg=f"{fn} trial {trial} d={d} n={n}")
 
@@ -93,7 +93,7 @@ def test_multinomial_golden_weights(shim, internals_small):
     it = internals_small
     for k in range(int(it["n_picks"])):
         mult = it[f"p{k}_counts"]
-        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async", "host_multinomial_async_bf"):
             got = _multi(shim, 5, int(it[f"p{k}_n_obs"]), mult / mult.sum(), int(it["num_boot"]), fn)
             np.testing.assert_array_equal(got.T, it[f"p{k}_weights"])
 
@@ -120,10 +120,12 @@ def test_guarded_fast_binomial_matches_numpy(shim, n, p):
 
 
 @pytest.mark.parametrize("which", ["plain", "perturbed"])
-def test_resumable_samplers_multinomial_stress(shim, shim_perturbed, which):
+@pytest.mark.parametrize("fn", ["host_multinomial_async", "host_multinomial_async_bf"])
+def test_resumable_samplers_multinomial_stress(shim, shim_perturbed, which, fn):
     """The phase-wise (resumable) form of the samplers that the lane-asynchronous tile kernel runs: C3-like chains and chains
     with long inversion searches (n p up to 30: the search continues over several passes), > 2.5e6 draws, every weight numpy's;
-    also with the cheap primitives perturbed."""
+    also with the cheap primitives perturbed; ``host_multinomial_async_bf``: the branch-free forms of the common phases, called on
+    every pass whatever the lane's state, as the kernel calls them."""
     lib = shim if which == "plain" else shim_perturbed
     rng = np.random.default_rng(21)
     draws = 0
@@ -138,7 +140,7 @@ def test_resumable_samplers_multinomial_stress(shim, shim_perturbed, which):
         pv = mult / mult.sum()
         B = 400
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
-        got = _multi(lib, 5, n, pv, B, "host_multinomial_async")
+        got = _multi(lib, 5, n, pv, B, fn)
         np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial} d={d} n={n}")
         draws += (d - 1) * B
     inv_fb, f_fb = _fallbacks(lib)

@@ -112,7 +112,7 @@ def main():
             if ph.any():
                 per = ph.sum(axis=0) / wt[:, 2].sum()
                 print("   async stamps, shader cycles per pass: " + ", ".join(f"{n} {v:.0f}" for n, v in zip(
-                    ["retire/restart", "start", "inversion", "BTPE attempt", "explicit", "squeeze", "exact redo"], per)) + f"; sum {per.sum():.0f}", flush=True)
+                    ["retire/restart", "start (both set-ups)", "inversion segment + attempt", "attempt outside the triangle", "explicit", "squeeze", "exact redo"], per)) + f"; sum {per.sum():.0f}", flush=True)
         if bs.n_tiles:
             wt = raw[: bs.n_tiles * 4].reshape(-1, 4)
             dur = (wt[:, 1] - wt[:, 0]) / 1e8
