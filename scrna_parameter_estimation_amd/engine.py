@@ -446,6 +446,11 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
 CHAIN_SLOT = 1 << 62      # include/memento_hip.h: MM_CHAIN_SLOT
 CHAIN_LONE = __import__('os').environ.get('MM_CHAIN_LONE', '1') != '0'        # (env overrides: measurement tools)
 CHAIN_MIN_K = int(__import__('os').environ.get('MM_CHAIN_MIN_K', '0'))
+# FEW chains (a gene shard of a multi-GPU run): with at most this many chains in a launch every chain gets a wave of its own --
+# three rounds of the chip's wave slots at most; lane-sharing tiles only pay when there are far more chains than wave slots.
+# Measured on the 8 / 4 / 2 cost-balanced gene shards of C3 (5.4k / 10.8k / 21.6k chains; bench.py --predict-shards): all chains one
+# per wave 1.71-2.49 s / 3.13-3.19 s / 6.0 s per shard against 2.53-2.87 / 2.98-3.09 / 3.2-3.3 s with tiles + lone chains.
+CHAIN_ALL_MAX = int(__import__('os').environ.get('MM_CHAIN_ALL_MAX', '8192'))
 # The other chains: TILE_MODE "async" = lane-asynchronous tile kernel (mm_boot1d_async: every lane walks its own chain at its
 # own pace, 64 chains of similar length per wave; chains with >= ASYNC_CHAIN_MIN_K bins go one per wave to mm_boot1d_chain);
 # "lockstep" = round 1-2's tile kernel (mm_boot1d_replay with the cost-model packing below; kept for A/B runs and the 2D path).
@@ -656,6 +661,8 @@ class Bootstrap1D:
         order_all = act[np.argsort(-self.K[act], kind="stable")]
         # the longest chains run one per wave (mm_boot1d_chain), the others one per lane of a tile (mm_boot1d_replay)
         n_chain = 0 if (fast or not CHAIN_MIN_K) else int(np.searchsorted(-self.K[order_all], -CHAIN_MIN_K, side="right"))
+        if not fast and target_waves is None and 0 < len(order_all) <= CHAIN_ALL_MAX:
+            n_chain = len(order_all)
         use_async = TILE_MODE == "async" and not fast and target_waves is None
         if use_async and ASYNC_CHAIN_MIN_K:
             n_chain = max(n_chain, int(np.searchsorted(-self.K[order_all], -ASYNC_CHAIN_MIN_K, side="right")))

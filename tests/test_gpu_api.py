@@ -66,10 +66,15 @@ def _design(memento, adata, g):
     return cov, trt
 
 
+@pytest.mark.parametrize("chain_all_max", [8192, 0])
 @pytest.mark.parametrize("fx", ["api_small", "api_approx", "api_meanonly"])
-def test_ht_1d_strict_replay_matches_reference(fx, request):
+def test_ht_1d_strict_replay_matches_reference(fx, request, chain_all_max, monkeypatch):
     """strict=True replays the reference's global np.random stream (num_cpus=1 semantics): coefficients,
-    standard errors and p-values must match the real reference's output."""
+    standard errors and p-values must match the real reference's output -- with every chain in a wave of its own (the default for
+    launches of few chains: mm_boot1d_chain) and with the lane-per-chain tile kernel (engine.CHAIN_ALL_MAX = 0)."""
+    from scrna_parameter_estimation_amd import engine
+
+    monkeypatch.setattr(engine, "CHAIN_ALL_MAX", chain_all_max)
     g = request.getfixturevalue(fx)
     memento, adata = _run_to_moments(g)
     cov, trt = _design(memento, adata, g)
@@ -83,6 +88,8 @@ def test_ht_1d_strict_replay_matches_reference(fx, request):
     # reference as well (p-values of noise): only the DE p-values are meaningful there.
     for k in (["mean_asl"] if fx == "api_meanonly" else ["mean_asl", "var_asl"]):
         np.testing.assert_allclose(ht[k], g["ht_" + k], rtol=1e-5, atol=1e-12, equal_nan=True, err_msg=k)
+    bs = adata.uns["memento"]["_hip"].last_bootstrap
+    assert (bs.n_tiles == 0) == (chain_all_max > 0) and bs.n_chain > 0
     df = memento.get_1d_ht_result(adata)
     assert list(df.columns) == ["gene", "tx", "de_coef", "de_se", "de_pval", "dv_coef", "dv_se", "dv_pval"]
     assert len(df) == len(g["gene_list"])

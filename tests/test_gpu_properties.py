@@ -191,6 +191,7 @@ def test_three_replay_kernels_agree_bit_for_bit(big, monkeypatch):
         monkeypatch.setattr(engine, "ASYNC_CHAIN_MIN_K", 0)
         monkeypatch.setattr(engine, "CHAIN_MIN_K", min_k)
         monkeypatch.setattr(engine, "CHAIN_LONE", False)
+        monkeypatch.setattr(engine, "CHAIN_ALL_MAX", 0)
         bs = engine.Bootstrap1D(blocks, genes, maxx, sf_bin, sf_table, np.full(ng, 0.07), B)
         r = np.random.default_rng(4).random((2, bs.n_pairs))
         zeros = np.zeros(bs.n_pairs)
@@ -231,6 +232,7 @@ def test_replay_weights_bit_exact_at_scale(big, monkeypatch, tile_mode):
     monkeypatch.setattr(engine, "CHAIN_MIN_K", int(np.median(bs.K[bs.K >= 2])) + 1)
     monkeypatch.setattr(engine, "TILE_MODE", tile_mode)
     monkeypatch.setattr(engine, "ASYNC_CHAIN_MIN_K", 0)
+    monkeypatch.setattr(engine, "CHAIN_ALL_MAX", 0)
     bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
     n_draws = 0
     assert bs.n_chain > 0 and (bs.n_async if tile_mode == "async" else bs.n_tiles) > 0          # both kernels are exercised
