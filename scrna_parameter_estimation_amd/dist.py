@@ -72,19 +72,19 @@ def gather_1d_ht(comm, names, out, gene_pos=None, n_tests=None):
     if n_tests is None:
         per = len(out[k0]) // max(1, len(names))
         n_tests = np.full(len(names), per, dtype=np.int64)
-    parts = comm.allgather_objects({"names": names, "pos": None if gene_pos is None else np.asarray(gene_pos, dtype=np.int64),
-                                    "nt": np.asarray(n_tests, dtype=np.int64), "out": {k: np.asarray(v) for k, v in out.items()}})
-    if any(p_["pos"] is None for p_ in parts):
-        all_names = [n for p_ in parts for n in p_["names"]]
-        return all_names, {k: np.concatenate([p_["out"][k] for p_ in parts]) for k in out}
-    pos = np.concatenate([p_["pos"] for p_ in parts])
-    nt = np.concatenate([p_["nt"] for p_ in parts])
-    cat_names = np.array([n for p_ in parts for n in p_["names"]], dtype=object)
+    # the numeric vectors travel as tensors through the backend's all-gather (RCCL on GPUs); only the gene names go as objects
+    cat = {k: comm.allgather_concat(np.asarray(v, dtype=np.float64)) for k, v in out.items()}
+    nt = comm.allgather_concat(np.asarray(n_tests, dtype=np.float64)).astype(np.int64)
+    name_parts = comm.allgather_objects(names)
+    cat_names = np.array([n for part in name_parts for n in part], dtype=object)
+    have_pos = comm.allgather_concat(np.array([0.0 if gene_pos is None else 1.0]))
+    if not have_pos.all():
+        return cat_names.tolist(), cat
+    pos = comm.allgather_concat(np.asarray(gene_pos, dtype=np.float64)).astype(np.int64)
     order = np.argsort(pos, kind="stable")
     first = np.concatenate([[0], np.cumsum(nt)])[:-1]                    # first test of every gene in the rank-order concatenation
     idx = np.concatenate([np.arange(first[g], first[g] + nt[g]) for g in order]) if len(order) else np.zeros(0, dtype=np.int64)
-    full = {k: np.concatenate([p_["out"][k] for p_ in parts])[idx] for k in out}
-    return cat_names[order].tolist(), full
+    return cat_names[order].tolist(), {k: v[idx] for k, v in cat.items()}
 
 
 def shard_stream_uniforms(comm, gene_pos, live):

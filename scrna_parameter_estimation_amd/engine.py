@@ -1058,6 +1058,7 @@ class Bootstrap2D:
         tile_ptr = np.concatenate([[0], np.cumsum(tile_k.astype(np.int64))]).astype(np.int64)
         rows = int(tile_ptr[-1])
         self.draws_per_replicate = int(np.maximum(self.K[order] - 1, 0).sum())
+        self.wave_steps_per_replicate = rows
         ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(6)]
         d_pair_slot, d_tile_ptr = dev(pair_slot), dev(tile_ptr)
         status = zeros((1,), torch.int32)

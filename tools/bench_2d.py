@@ -39,4 +39,12 @@ ht = adata.uns["memento"]["2d_ht"]
 bs = adata.uns["memento"]["_hip"].last_bootstrap2d
 print(f"pairs={len(pairs)} compute_2d={t1-t0:.3f}s ht_2d={t2-t1:.3f}s -> {len(pairs)/(t2-t0):.1f} pair-tests/s; K mean {bs.K.mean():.0f} max {bs.K.max()}; finite p {np.isfinite(ht['corr_asl']).mean():.3f}")
 from scrna_parameter_estimation_amd import engine
+st = adata.uns["memento"]["_hip"]
+# algorithmic bytes of the pair kernels: every pair reads its partner column's entries (4 B each) in every block
+name_col = {n: i for i, n in enumerate(names)}
+nnz_gene = st.blocks.blk_cnt.astype(np.int64).sum(axis=0)[st.gene_idx]
+right_bytes = 4 * int(sum(nnz_gene[name_col[b]] for _, b in pairs))
+rows = int(getattr(bs, "wave_steps_per_replicate", 0))
+print(f"pair kernels: partner-column entries read per pass {right_bytes / 1e9:.2f} GB; last replay chunk: {bs.n_tiles} tiles, "
+      f"{bs.draws_per_replicate} useful draws and {rows} wave-steps per replicate -> lane occupancy {bs.draws_per_replicate / max(1, rows * 64):.3f}")
 print("packing:", {k: (round(v, 1) if isinstance(v, float) else v) for k, v in engine.PACK_LAST.items()})
