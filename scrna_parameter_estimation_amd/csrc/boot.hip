@@ -577,28 +577,7 @@ __global__ __launch_bounds__(256, ASYNC_MIN_WAVES) void k_boot1d_async(const dou
       k++;
       cur = nxt;                                                 // record k
       if (dn <= 0 || k == K - 1) {
-        if (dn > 0) {                                            // every bin but the last has drawn: the last one takes the rest
-          if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = dn;
-          double wd = (double)dn;
-          M1 += (cur.v * wd) * cur.a;
-          M2 += ((cur.v * cur.v) * wd) * cur.b - ((omq * cur.v) * wd) * cur.b;
-        }
-        double mean = M1 / nobs;
-        double var = M2 / nobs - mean * mean;
-        if (mean_only) {
-          mean = mean + 1;
-          var = 10.0;
-        }
-        om[r] = mean;
-        ov[r] = var;
-        r++;
-        if (r < num_boot) {
-          cur = load_bin(rec);                                   // in flight until the lane starts its next replicate (next pass)
-          nxt = load_bin(rec + 8);
-          state = LS_RESTART;
-        } else {
-          state = LS_IDLE;
-        }
+        state = LS_FINISH;                                       // the replicate is complete: closed in one of the passes below
       } else {
         nxt = load_bin(rec + (int64_t)(k + 1) * 8);              // k + 1 <= K - 1
         state = LS_START;
@@ -609,6 +588,33 @@ __global__ __launch_bounds__(256, ASYNC_MIN_WAVES) void k_boot1d_async(const dou
       dn = n;
       k = 0;
       state = LS_START;
+    }
+    // closing a replicate (the last bin's remainder, two fp64 divisions, the stores, the next replicate's first operands) is ~100
+    // dependent instructions that some lane of a 64-wide wave needs on nearly every pass: done every fourth pass, for all lanes
+    // that wait for it (a lane loses 1.5 passes per replicate on average, every other lane saves the time on three passes in four)
+    if ((passes & 3) == 0 && state == LS_FINISH) {
+      if (dn > 0) {                                              // every bin but the last has drawn: the last one takes the rest
+        if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = dn;
+        double wd = (double)dn;
+        M1 += (cur.v * wd) * cur.a;
+        M2 += ((cur.v * cur.v) * wd) * cur.b - ((omq * cur.v) * wd) * cur.b;
+      }
+      double mean = M1 / nobs;
+      double var = M2 / nobs - mean * mean;
+      if (mean_only) {
+        mean = mean + 1;
+        var = 10.0;
+      }
+      om[r] = mean;
+      ov[r] = var;
+      r++;
+      if (r < num_boot) {
+        cur = load_bin(rec);                                     // in flight until the lane starts its next replicate (next pass)
+        nxt = load_bin(rec + 8);
+        state = LS_RESTART;
+      } else {
+        state = LS_IDLE;
+      }
     }
     ASYNC_STAMP(0);
     // ---- the draw of bin k, phase by phase (csrc/npy_rng.h) ------------------------------------------------------------------
@@ -629,12 +635,12 @@ __global__ __launch_bounds__(256, ASYNC_MIN_WAVES) void k_boot1d_async(const dou
     if (state == LS_EXPL) state = lane_expl(D);
     ASYNC_STAMP(4);
     // the rarer phases do not run on every pass: a lane in one of them waits a pass or a few, every other lane saves the time
-    // (squeeze / Stirling: ~3 % of the lanes, every second pass; the exact redo: ~0.3 % of the draws, every eighth pass)
+    // (squeeze / Stirling: ~3 % of the lanes, every second pass; the exact redo: ~0.3 % of the draws, every 32nd pass)
     if ((passes & 1) == 0) {
       if (state == LS_SQZ) state = lane_sqz(D);
     }
     ASYNC_STAMP(5);
-    if ((passes & 7) == 0) {
+    if ((passes & 31) == 0) {
       if (state == LS_XINV) state = lane_xinv(D, g);
       if (state == LS_XBT) state = lane_xbt(D, g);
     }

@@ -523,7 +523,7 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p
 // can run a fixed sequence of phases per pass, each for the lanes that are in it, and let every lane move on to its next bin as
 // soon as ITS draw is done (csrc/boot.hip: k_boot1d_async).  The arithmetic, the guards and the fallback rule are those of
 // binomial_inversion_fast / binomial_btpe_fast above: the draw and the uniforms it consumes are numpy's in every case.
-enum LaneState : int32_t { LS_START = 0, LS_INV, LS_ATT, LS_ATT2, LS_EXPL, LS_SQZ, LS_XINV, LS_XBT, LS_DONE, LS_RESTART, LS_IDLE };
+enum LaneState : int32_t { LS_START = 0, LS_INV, LS_ATT, LS_ATT2, LS_EXPL, LS_SQZ, LS_XINV, LS_XBT, LS_DONE, LS_FINISH, LS_RESTART, LS_IDLE };
 
 struct LaneDraw {
   int32_t n;                 // cells left when the draw starts
