@@ -299,6 +299,19 @@ NPY_HD float f_log1p_small(float d) {
   float t = d * f_rcp(2.0f + d), t2 = t * t;
   return 2.0f * t * (1.0f + t2 * (0.333333333f + t2 * (0.2f + t2 * (0.142857143f + t2 * 0.111111111f))));
 }
+// log(1 + d) for any d > -1: the series above for |d| <= 0.35, the fp32 logarithm of 1 + d beyond (absolute error <= 5e-7 |log| + 2e-7:
+// callers that multiply it by c add ~1e-6 c to their guard, see binomial_btpe_fast)
+#ifndef NPY_BTPE_ANYD
+#define NPY_BTPE_ANYD 1       // 0: log1p arguments beyond 0.35 send the draw to the exact redo (round 2)
+#endif
+NPY_HD float f_log1p_any(float d) {
+  if (!NPY_BTPE_ANYD) return f_log1p_small(d);
+  return fabsf(d) <= 0.35f ? f_log1p_small(d) : f_log(1.0f + d);
+}
+NPY_HD float f_stirling_true(float x) {       // Stirling's series itself, 1/(12x) - 1/(360x^3) + 1/(1260x^5) - 1/(1680x^7) + 1/(1188x^9): numpy's
+  float ix = f_rcp(x), ix2 = ix * ix;          // btpe_stirling carries 13680 where the series has 13860 = 166320/12 (reproduced there, not here)
+  return (13860.0f - (462.0f - (132.0f - (99.0f - 140.0f * ix2) * ix2) * ix2) * ix2) * ix * (1.0f / 166320.0f);
+}
 NPY_HD float f_stirling(float x) {            // btpe_stirling in fp32: ~1/(12 x), a small correction term
   float ix = f_rcp(x), ix2 = ix * ix;
   return (13680.0f - (462.0f - (132.0f - (99.0f - 140.0f * ix2) * ix2) * ix2) * ix2) * ix * (1.0f / 166320.0f);
@@ -306,6 +319,9 @@ NPY_HD float f_stirling(float x) {            // btpe_stirling in fp32: ~1/(12 x
 
 #ifndef NPY_INV_GUARD
 #define NPY_INV_GUARD 1.5e-4f // absolute, on U - CDF.  fp32 error of exp + recurrence + running subtraction: worst-case bound 4e-5 for X <= 60, largest seen in 2e7 random draws 8e-6
+#endif
+#ifndef NPY_BTPE_LOGF
+#define NPY_BTPE_LOGF 1       // binomial_btpe_fast: the explicit-product acceptance test through the closed log form where that is accurate
 #endif
 #ifndef NPY_F_GUARD
 #define NPY_F_GUARD 2e-4f     // relative, on v vs f(y)/f(m): fp32 error of a product of <= 64 factors < 3e-5
@@ -469,42 +485,59 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p
     Int y = (Int)fx;
     Int k = y > m ? y - m : m - y;
     NPY_ST(3);
-    if (!((k > 20) && ((double)k < nrq / 2.0 - 1))) {
+    // numpy accepts through the explicit product F = f(y)/f(m) (k factors) when k <= 20 or k >= nrq/2 - 1, and through the squeeze +
+    // Stirling-corrected log form otherwise.  The log form IS log F (up to the truncation of the Stirling series, < 1e-9 for arguments
+    // >= 8), so the explicit case can take it too -- no loop of up to 64 factors that every lane of a wave waits for: v <= F iff
+    // log v <= bound.  The product is kept for small arguments and large log1p arguments.
+    const bool expl = !((k > 20) && ((double)k < nrq / 2.0 - 1));
+    float yf1 = (float)y + 1.0f;                                        // x1
+    float wf = (float)(n - y) + 1.0f;                                   // w
+    float d1 = (float)(m - y) * f_rcp(yf1);                             // f1/x1 - 1 = (m - y)/(y + 1)
+    float d2 = (float)(y - m) * f_rcp(wf);                              // z/w - 1 = (y - m)/(n - y + 1)
+    double num3 = ((double)n + 2.0) * r - ((double)y + 1.0);            // w r - x1 q, without the cancellation
+    float d3 = (float)num3 * f_rcp(yf1 * (float)q);                     // w r/(x1 q) - 1
+    const bool small_d = !(fabsf(d1) > 0.35f || fabsf(d2) > 0.35f || fabsf(d3) > 0.35f);
+    const bool sane_d = d1 > -0.9f && d2 > -0.9f && d3 > -0.9f && d1 < 8.0f && d2 < 8.0f && d3 < 8.0f;   // the fp32 logarithm's range of use
+    const Int amin = (y < m ? y : m) < (n - (y > m ? y : m)) ? (y < m ? y : m) : (n - (y > m ? y : m));
+    if (expl && !(NPY_BTPE_LOGF && small_d && amin >= (Int)7)) {
       int dec = btpe_explicit_fast<Int>(v, n, m, y, r, NPY_KEEP(tk, q, r));
       NPY_ST(4);
       if (dec < 0) return -1;
       if (dec == 0) continue;
       return y;
     }
-    // squeeze, then the Stirling-corrected bound
     if (v < 1e-11) {
       if (v > -1e-11) return -1;
-      return y;                          // numpy: log of a negative number is NaN, every comparison fails, the draw is accepted
+      return y;       // numpy: v <= 0 < F (explicit case); log of a negative number is NaN and every comparison fails (squeeze case): accepted
     }
-    const float rnrq = f_rcp((float)NPY_KEEP(tk, nrq, r));
-    float kf = (float)k;
-    float rho = (kf * rnrq) * ((kf * (kf * 0.333333333f + 0.625f) + 0.16666666666666666f) * rnrq + 0.5f);
-    float t = -(kf * kf) * 0.5f * rnrq;
     float A = f_log((float)v);
-    float gs = 1e-5f * (1.0f + fabsf(A)) + 6e-6f * (fabsf(t) + rho);
-    float lo_ = t - rho, hi_ = t + rho;
-    NPY_ST(5);
-    if (A < lo_ - gs) return y;
-    if (A > hi_ + gs) continue;
-    if (A < lo_ + gs || A > hi_ - gs) return -1;
-    float yf1 = (float)y + 1.0f;                                        // x1
-    float d1 = (float)(m - y) * f_rcp(yf1);                             // f1/x1 - 1 = (m - y)/(y + 1)
-    float wf = (float)(n - y) + 1.0f;                                   // w
-    float d2 = (float)(y - m) * f_rcp(wf);                              // z/w - 1 = (y - m)/(n - y + 1)
-    double num3 = ((double)n + 2.0) * r - ((double)y + 1.0);            // w r - x1 q, without the cancellation
-    float d3 = (float)num3 * f_rcp(yf1 * (float)q);                     // w r/(x1 q) - 1
-    if (fabsf(d1) > 0.35f || fabsf(d2) > 0.35f || fabsf(d3) > 0.35f) return -1;
-    float T1 = (float)xm * f_log1p_small(d1);
-    float T2 = ((float)(n - m) + 0.5f) * f_log1p_small(d2);
-    float T3 = (float)(y - m) * f_log1p_small(d3);
+    if (!expl) {      // squeeze
+      const float rnrq = f_rcp((float)NPY_KEEP(tk, nrq, r));
+      float kf = (float)k;
+      float rho = (kf * rnrq) * ((kf * (kf * 0.333333333f + 0.625f) + 0.16666666666666666f) * rnrq + 0.5f);
+      float t = -(kf * kf) * 0.5f * rnrq;
+      float gs = 1e-5f * (1.0f + fabsf(A)) + 6e-6f * (fabsf(t) + rho);
+      float lo_ = t - rho, hi_ = t + rho;
+      NPY_ST(5);
+      if (A < lo_ - gs) return y;
+      if (A > hi_ + gs) continue;
+      if (A < lo_ + gs || A > hi_ - gs) return -1;
+      if (!(NPY_BTPE_ANYD ? sane_d : small_d)) return -1;
+    }
+    // (a bin with n r of 30-100 and a candidate 21+ away from the mode has |d| > 0.35: the fp32 logarithm then, with its absolute
+    // error in the guard -- these were 80 % of the draws that went to the exact redo)
+    const float c1 = (float)xm, c2 = (float)(n - m) + 0.5f, c3 = (float)(y - m);
+    float T1 = c1 * f_log1p_any(d1);
+    float T2 = c2 * f_log1p_any(d2);
+    float T3 = c3 * f_log1p_any(d3);
     const float mf1 = (float)NPY_KEEP(tk, m, y) + 1.0f, zf = (float)(n - NPY_KEEP(tk, m, y)) + 1.0f;
-    float bound = T1 + T2 + T3 + f_stirling(mf1) + f_stirling(zf) + f_stirling(yf1) + f_stirling(wf);
+    // log(f(y)/f(m)) = T1 + T2 + T3 + st(f1) + st(z) - st(x1) - st(w) (Stirling's series for the four factorials).  numpy's test for
+    // k > 20 adds all four correction terms, with 13680 for the series' 13860 (as numpy's source has it): reproduced as it is there; the
+    // explicit case compares with the true F, so it gets the true signs and the true series.
+    float bound = T1 + T2 + T3 + (expl ? (f_stirling_true(mf1) + f_stirling_true(zf)) - (f_stirling_true(yf1) + f_stirling_true(wf))
+                                       : f_stirling(mf1) + f_stirling(zf) + f_stirling(yf1) + f_stirling(wf));
     float gb = 4e-6f * (fabsf(T1) + fabsf(T2) + fabsf(T3)) + 1e-5f * (1.0f + fabsf(A));
+    if (!small_d) gb += 1e-6f * ((fabsf(d1) > 0.35f ? c1 : 0.0f) + (fabsf(d2) > 0.35f ? c2 : 0.0f) + (fabsf(d3) > 0.35f ? fabsf(c3) : 0.0f));
     NPY_ST(6);
     if (A > bound + gb) continue;
     if (A < bound - gb) return y;

@@ -6,6 +6,7 @@ include/memento_hip.h.  Nothing in this module has a CPU fallback.
 """
 
 import ctypes
+import os
 
 from ctypes import c_void_p
 
@@ -444,19 +445,19 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
 # steps in 0.75 us there against 0.96-1.2 us as the only lane of a tile wave.  CHAIN_MIN_K > 0: in addition every chain with at
 # least that many bins (tests / tools; 2 = all of them).  Both kernels replay the same draws, bit for bit.
 CHAIN_SLOT = 1 << 62      # include/memento_hip.h: MM_CHAIN_SLOT
-CHAIN_LONE = __import__('os').environ.get('MM_CHAIN_LONE', '1') != '0'        # (env overrides: measurement tools)
-CHAIN_MIN_K = int(__import__('os').environ.get('MM_CHAIN_MIN_K', '0'))
+CHAIN_LONE = os.environ.get('MM_CHAIN_LONE', '1') != '0'        # (the MM_* environment overrides below exist for the measurement tools)
+CHAIN_MIN_K = int(os.environ.get('MM_CHAIN_MIN_K', '0'))
 # FEW chains (a gene shard of a multi-GPU run): with at most this many chains in a launch every chain gets a wave of its own --
 # three rounds of the chip's wave slots at most; lane-sharing tiles only pay when there are far more chains than wave slots.
 # Measured on the 8 / 4 / 2 cost-balanced gene shards of C3 (5.4k / 10.8k / 21.6k chains; bench.py --predict-shards): all chains one
 # per wave 1.71-2.49 s / 3.13-3.19 s / 6.0 s per shard against 2.53-2.87 / 2.98-3.09 / 3.2-3.3 s with tiles + lone chains.
-CHAIN_ALL_MAX = int(__import__('os').environ.get('MM_CHAIN_ALL_MAX', '8192'))
+CHAIN_ALL_MAX = int(os.environ.get('MM_CHAIN_ALL_MAX', '8192'))
 # The other chains: TILE_MODE "async" = lane-asynchronous tile kernel (mm_boot1d_async: every lane walks its own chain at its
 # own pace, 64 chains of similar length per wave; chains with >= ASYNC_CHAIN_MIN_K bins go one per wave to mm_boot1d_chain);
 # "lockstep" = round 1-2's tile kernel (mm_boot1d_replay with the cost-model packing below; kept for A/B runs and the 2D path).
-TILE_MODE = __import__('os').environ.get('MM_TILE_MODE', 'lockstep')
-ASYNC_CHAIN_MIN_K = int(__import__('os').environ.get('MM_ASYNC_CHAIN_MIN_K', '160'))
-ASYNC_LANES = int(__import__('os').environ.get('MM_ASYNC_LANES', '64'))      # chains per wave of the async kernel (the other lanes idle)
+TILE_MODE = os.environ.get('MM_TILE_MODE', 'lockstep')
+ASYNC_CHAIN_MIN_K = int(os.environ.get('MM_ASYNC_CHAIN_MIN_K', '160'))
+ASYNC_LANES = int(os.environ.get('MM_ASYNC_LANES', '64'))      # chains per wave of the async kernel (the other lanes idle)
 CHAIN_CLOCK_OFF = 1 << 18   # int64 offset of the chain kernel's records in the mm_debug_wave_clock buffer (tools/)
 
 PAIR_SLOTS = 1024      # SIMDs: tiles t and t + PAIR_SLOTS share one
@@ -506,10 +507,10 @@ def pcg64_jump_table(seed=5):
     return _JUMP_CACHE[seed]
 
 
-REPLAY_RING = __import__('os').environ.get('MM_REPLAY_RING', '0') != '0'       # tile kernel: uniforms produced ahead into an LDS ring (mm_debug_replay_ring);
+REPLAY_RING = os.environ.get('MM_REPLAY_RING', '0') != '0'       # tile kernel: uniforms produced ahead into an LDS ring (mm_debug_replay_ring);
                             # OFF: measured slower at every top-up rate (C3: 3.61 / 3.71 / 3.80 s with 2 / 3 / 4 per step against 3.53 s)
 _STREAM_CACHE = {}
-STREAM_TABLE = __import__('os').environ.get('MM_STREAM_TABLE', '0') != '0'     # tile kernel: uniforms from the precomputed stream table;
+STREAM_TABLE = os.environ.get('MM_STREAM_TABLE', '0') != '0'     # tile kernel: uniforms from the precomputed stream table;
                             # OFF: measured slower (C3: 4.12-4.16 s against 3.53 s -- a wave's lanes sit at 64 different places of the
                             # table, and the gather's latency is exposed in every attempt; profiles/README.md)
 STREAM_PER_STEP = 3.0       # table length = this x (longest tile chain's steps) x replicates: a draw takes 1 (inversion) or 2 per
@@ -787,7 +788,7 @@ class Bootstrap1D:
                       int(fill_seed) & ((1 << 64) - 1), B, int(mean_only), ld, P(self.ym), P(self.yv), s)
         elif n_tiles:
             _lib.call("mm_debug_replay_ring", 1 if REPLAY_RING else 0)
-            _lib.call("mm_debug_replay_rows_mod", int(__import__('os').environ.get('MM_DEBUG_ROWS_MOD', '0')))      # timing experiments only
+            _lib.call("mm_debug_replay_rows_mod", int(os.environ.get('MM_DEBUG_ROWS_MOD', '0')))      # timing experiments only
             d_tab, tab_len, tab_over = None, 0, None
             if STREAM_TABLE and int(tile_k.max()) > 1:
                 tab_len = int(STREAM_PER_STEP * (int(tile_k.max()) - 1) * B) + 4096

@@ -16,11 +16,12 @@ int main(int argc,char**argv){
   long mism=0, done=0, fast_ok=0;
   for(long it=0; it<N; it++){
     int64_t n; double p;
-    int mode = it%4;
+    int mode = it%5;
     if(mode==0){ n=(int64_t)std::pow(10.0,1.8+4.2*u01(rng)); p=0.5*u01(rng); }
     else if(mode==1){ n=(int64_t)std::pow(10.0,3+6*u01(rng)); double np_=30.0+std::pow(10.0,4*u01(rng)); p=np_/n; }
     else if(mode==2){ n=40000+(int64_t)(20000*u01(rng)); p=std::pow(10.0,-3.2+2.9*u01(rng)); }
-    else { n=(int64_t)(61+1000*u01(rng)); p=0.5-0.5*std::pow(u01(rng),3); }
+    else if(mode==3){ n=(int64_t)(61+1000*u01(rng)); p=0.5-0.5*std::pow(u01(rng),3); }
+    else { n=(int64_t)std::pow(10.0,1.8+5.2*u01(rng)); p=(30.0+120.0*u01(rng))/(double)n; }   // n p in [30, 150]: small m, the log form of the explicit test near its limits
     if(p>0.5) p=0.5; if(n>= (1LL<<31)-2) continue; if(p*(double)n<=30.0) continue;
     npyrng::Pcg64 g0{rng(),rng(),rng(),rng()|1};
     npyrng::Pcg64 a=g0,b=g0;
