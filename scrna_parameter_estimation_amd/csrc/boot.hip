@@ -142,6 +142,12 @@ __global__ __launch_bounds__(256) void k_pcg64_stream(double *__restrict__ out, 
 #ifndef BOOT_RING_ROUNDS
 #define BOOT_RING_ROUNDS 2       // uniforms every lane produces ahead per bin step in ring mode (a lane uses ~1.5 on average)
 #endif
+#ifndef BOOT_BTPE_CAP
+#define BOOT_BTPE_CAP 1          // BTPE attempts a lane makes per bin step of its tile (0: as many as the draw takes, every lane waiting)
+#endif
+#ifndef BOOT_TAIL_LANES
+#define BOOT_TAIL_LANES 4        // with at most this many lanes still inside the replicate, draws run to completion
+#endif
 template <int MINW, bool FAST, int TAB>
 __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v, const double *__restrict__ a,
@@ -226,14 +232,25 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
     double M1 = 0.0, M2 = 0.0;
     int32_t dn = n;
     bool live = true;
-    for (int k = 0; k < kmax; k++) {
-      int kn = k + 1 < kmax ? k + 1 : 0;
+    // The lanes share the instruction stream, not the bin index: a BTPE draw makes BOOT_BTPE_CAP attempt(s) per bin step, and a lane
+    // whose attempts were all rejected stays on its bin and tries again in the next step, beside its neighbours' next draws
+    // (binomial_pre_capped) -- so a step costs the wave one attempt, not as many as its unluckiest lane needs.  The lanes meet again
+    // at the end of the replicate; while only stragglers (<= BOOT_TAIL_LANES lanes) are left, draws run to completion.
+    int kl = 0;
+    for (;;) {
+      const bool act = run && kl < K;
+      const uint64_t act_mask = __ballot(act);
+      if (act_mask == 0) break;
+      const int cap = (BOOT_BTPE_CAP > 0 && __popcll(act_mask) > BOOT_TAIL_LANES) ? BOOT_BTPE_CAP : 0;
+      int kn = kl + 1 < K ? kl + 1 : 0;
       int64_t on = obase + (int64_t)kn * 64;
       double n_pk = pk_[on], n_lq = lq_[on], n_v = v[on], n_a = a[on], n_b = b[on];
       if constexpr (TAB == 2) g.top_up(BOOT_RING_ROUNDS);
-      if (run && k < K) {
+      bool adv = false;
+      if (act) {
         int32_t w;
-        if (k < K - 1) {
+        bool pending = false;
+        if (kl < K - 1) {
           w = 0;
           if (live) {
 #ifdef BOOT_STAMPS  // diagnostic build only (tools/replay_stamps.sh): where a wave-step spends its cycles.  Same draws.
@@ -254,13 +271,16 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
               bool bt = !zero && !inv;
               if (bt) {
                 NPY_CLOCK(stamp_bt[7]);
-                X = FAST ? npyrng::binomial_btpe_fast<int32_t>(g, dn, p, stamp_bt) : -1;
+                X = FAST ? npyrng::binomial_btpe_fast<int32_t>(g, dn, p, cap, stamp_bt) : -1;
                 cnt_bt++;
               }
               uint64_t s15;
               NPY_CLOCK(s15);
               stamp_fastcall += s15 - s1;
-              if (bt && X < 0) {
+              if (bt && X == -2) {
+                pending = true;
+                cnt_bt--;
+              } else if (bt && X < 0) {
                 cnt_fb++;
                 g.rewind(saved);
                 X = npyrng::binomial_btpe<int32_t>(g, dn, p);
@@ -271,22 +291,31 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
               w = zero ? 0 : (flip ? dn - X : X);
             }
 #else
-            w = npyrng::binomial_pre<int32_t, FAST>(g, c_pk, c_lq, dn);
+            if constexpr (FAST) w = npyrng::binomial_pre_capped<int32_t>(g, c_pk, c_lq, dn, cap, pending);
+            else w = npyrng::binomial_pre<int32_t, false>(g, c_pk, c_lq, dn);
 #endif
-            dn -= w;
-            if (dn <= 0) live = false;
+            if (!pending) {
+              dn -= w;
+              if (dn <= 0) live = false;
+            }
           }
         } else {
           w = dn > 0 ? dn : 0;
         }
-        if (w_dump) w_dump[((int64_t)slot * kmax_dump + k) * num_boot + r] = (int32_t)w;
-        if (w != 0) {
-          double wd = (double)w;
-          M1 += (c_v * wd) * c_a;
-          M2 += ((c_v * c_v) * wd) * c_b - ((omq * c_v) * wd) * c_b;
+        if (!pending) {
+          if (w_dump) w_dump[((int64_t)slot * kmax_dump + kl) * num_boot + r] = (int32_t)w;
+          if (w != 0) {
+            double wd = (double)w;
+            M1 += (c_v * wd) * c_a;
+            M2 += ((c_v * c_v) * wd) * c_b - ((omq * c_v) * wd) * c_b;
+          }
+          adv = true;
         }
       }
-      c_pk = n_pk; c_lq = n_lq; c_v = n_v; c_a = n_a; c_b = n_b;
+      if (adv) {
+        kl++;
+        c_pk = n_pk; c_lq = n_lq; c_v = n_v; c_a = n_a; c_b = n_b;
+      }
     }
     if (run) {
       double mean = M1 / nobs;

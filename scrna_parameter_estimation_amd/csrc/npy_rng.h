@@ -83,6 +83,14 @@ NPY_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 
 // state = state * MULT + inc  (mod 2^128); output = rotr64(hi ^ lo, hi >> 58) of the NEW state.
 NPY_HD uint64_t pcg64_next64(Pcg64 &g) {
+#ifdef NPY_ABLATE_PCG  // timing experiments only (wrong draws): what the 128-bit multiply of the generator costs
+  {
+    uint64_t x = g.s_lo;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    g.s_lo = x;
+    return x + g.s_hi;
+  }
+#endif
   const uint64_t M_HI = 2549297995355413924ULL, M_LO = 4865540595714422341ULL;
   uint64_t lo = g.s_lo * M_LO;
   uint64_t hi = mulhi64(g.s_lo, M_LO) + g.s_hi * M_LO + g.s_lo * M_HI;
@@ -345,14 +353,17 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
   // full-rate fp32 instructions (no conversion, no v_rcp_f32); lock-stepped lanes share the trip count anyway.
   // numpy restarts when X exceeds bound = min(n, np + 10 sqrt(npq + 1)) >= min(n, 10): the first nine steps can never reach it, so
   // the bound (a square root) is only worked out by searches that get that far.
-  const float nf1 = nf + 1.0f;
+  // the factor (n + 1 - x) s / x of the recurrence as one fused multiply-add, (n + 1) s * (1/x) - s (1/x a literal): its
+  // cancellation costs at most (n + 1)/(n + 1 - x) ulps of the factor, i.e. something only for n < ~120 near the end of the support,
+  // where it adds < 1e-5 to the absolute error of the running sum (bound in NPY_INV_GUARD's comment: 4e-5; the guard is 1.5e-4)
+  const float a_s = (nf + 1.0f) * s;
   const int32_t cap9 = n < (Int)9 ? (int32_t)n : 9;
 #pragma unroll
   for (int it = 1; it <= 9; it++) {
     if (!(Uf > px) || it > cap9) break;
     X = it;
     Uf -= px;
-    px = px * ((nf1 - (float)it) * s) * (1.0f / (float)it);
+    px = px * __builtin_fmaf(a_s, 1.0f / (float)it, -s);
   }
   if (X == 9 && Uf > px) {
     // stay strictly below numpy's bound (and below 60: longer searches are ~6 sigma events for n*p <= 30 and go to the exact path)
@@ -366,7 +377,7 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
       if (!(Uf > px) || it > cap) break;
       X = it;
       Uf -= px;
-      px = px * ((nf1 - (float)it) * s) * (1.0f / (float)it);
+      px = px * __builtin_fmaf(a_s, 1.0f / (float)it, -s);
     }
   }
   bool ok = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);   // also false when the search stopped at a cap
@@ -411,8 +422,11 @@ NPY_HD int btpe_explicit_fast(double v, Int n, Int m, Int y, double r, double q)
 // the caller then rewinds the generator and runs binomial_btpe (numpy's arithmetic).
 // What only the rarer branches need (1/c, 1/p1, 1/nrq, the Stirling terms) is computed inside them, behind NPY_KEEP: three draws
 // in four are accepted in the triangular region on the first attempt and pay for the set-up of p1 .. p4 only.
+// ``cap`` > 0 bounds the attempts of THIS call: -2 is returned when they were all rejected (decided, uniforms consumed) -- the
+// caller calls again for the same (n, r) and the draw goes on where it stopped, since the set-up depends on (n, r) only and the
+// attempts are independent (the lock-step tile kernel makes one attempt per bin step and lets the lane retry in the next).
 template <typename Int, bool LAZY = false, typename Gen>
-NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p <= 0.5
+NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r, int cap NPY_ST_PARAM) {   // r = p <= 0.5
   const double q = 1.0 - r;
   const double fm = (double)n * r + r;
   const double md = floor(fm);
@@ -443,7 +457,7 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p
   const double p4 = p3 + c * rlamr;
   const double gu = 1e-11 * p4;                                       // set-up values are within ~1e-15 (relative) of numpy's
   NPY_ST(0);
-  const int max_att = g.max_attempts();
+  const int max_att = cap > 0 ? cap : g.max_attempts();
   for (int attempt = 0; attempt < max_att; attempt++) {
     const bool tk = (Int)attempt <= n;   // always true (see NPY_KEEP)
     double u = pcg64_next_double(g) * p4;
@@ -543,7 +557,7 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r NPY_ST_PARAM) {   // r = p
     if (A < bound - gb) return y;
     return -1;
   }
-  return -1;
+  return cap > 0 ? (Int)-2 : (Int)-1;
 }
 
 // ---- resumable form: one binomial draw as a small state machine ---------------------------------------------------------
@@ -1078,9 +1092,9 @@ NPY_HD Int binomial_pre(Gen &g, double pk, double lq, Int n) {
       typename Gen::Mark saved = g.mark();
 #if defined(BOOT_STAMPS) && defined(__HIPCC__)
       uint64_t npy_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      X = binomial_btpe_fast<Int, LAZY>(g, n, p, npy_dummy);
+      X = binomial_btpe_fast<Int, LAZY>(g, n, p, 0, npy_dummy);
 #else
-      X = binomial_btpe_fast<Int, LAZY>(g, n, p);
+      X = binomial_btpe_fast<Int, LAZY>(g, n, p, 0);
 #endif
       if (X < 0) {
         NPY_NOTE_FALLBACK(1);
@@ -1091,6 +1105,44 @@ NPY_HD Int binomial_pre(Gen &g, double pk, double lq, Int n) {
       X = binomial_btpe<Int>(g, n, p);
     }
 #endif
+  }
+  return flip ? n - X : X;
+}
+
+// binomial_pre<Int, true> with at most ``cap`` BTPE attempts in this call: ``pending`` is set (and the return value is
+// meaningless) when they were all rejected; calling again with the same arguments continues the draw.  A draw that falls inside a
+// guard in a later call is redone in numpy's arithmetic from the generator's position at THAT call: the rejected attempts before
+// it were decided outside every guard, so numpy's loop rejects them too and arrives at the same position with the same set-up.
+template <typename Int, typename Gen>
+NPY_HD Int binomial_pre_capped(Gen &g, double pk, double lq, Int n, int cap, bool &pending) {
+  pending = false;
+  if (n == 0 || pk == 0.0) return 0;
+  bool flip = !(pk <= 0.5);
+  double p = flip ? 1.0 - pk : pk;
+  Int X;
+  if (p * (double)n <= 30.0) {
+    double U = pcg64_next_double(g);
+    int32_t xf = binomial_inversion_fast<Int>(U, n, p, lq);
+    if (xf < 0) NPY_NOTE_FALLBACK(0);
+    X = xf >= 0 ? (Int)xf : binomial_inversion_pre<Int>(g, n, p, lq, U);
+  } else {
+    g.reserve(34);
+    typename Gen::Mark saved = g.mark();
+#if defined(BOOT_STAMPS) && defined(__HIPCC__)
+    uint64_t npy_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    X = binomial_btpe_fast<Int, false>(g, n, p, cap, npy_dummy);
+#else
+    X = binomial_btpe_fast<Int, false>(g, n, p, cap);
+#endif
+    if (X == (Int)-2) {
+      pending = true;
+      return 0;
+    }
+    if (X < 0) {
+      NPY_NOTE_FALLBACK(1);
+      g.rewind(saved);
+      X = binomial_btpe<Int>(g, n, p);
+    }
   }
   return flip ? n - X : X;
 }

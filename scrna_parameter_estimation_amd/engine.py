@@ -26,12 +26,23 @@ ORDER_BIG_CAP_2D = 4096
 PACK_C0 = 220.0
 PACK_C1 = 3.0
 PACK_WAVES = 2000
-PACK_WAVES3 = 2750       # tile target when a third wave per SIMD pays (pack_lanes)
+# tile target and constants when a third wave per SIMD pays (pack_lanes): 3 x 1024 slots.  Round 3: re-swept for the 1D tile kernel
+# that makes one BTPE attempt per bin step -- its wide tiles step 17 % faster, so the balance moves to fewer, wider tiles and more
+# lone chains (tools/pack_sweep.py, C3: 3.79 s with round 2's 220 / 3 / 2750, 3.24-3.26 s with these; C2, two waves per SIMD, keeps
+# 220 / 3: 267-270 ms against 283).  The 2D kernel keeps the constants it was tuned with.
+PACK3_C0 = 260.0
+PACK3_C1 = 2.2
+PACK_WAVES3 = 3050
+PACK2D = (220.0, 3.0, 220.0, 3.0, 2750)
 # (b) measured time of one bin step of a wave of L chains running as the OLDER wave of its SIMD, us (tools/replay_balance.py,
-# C3, round-2 kernel with the guarded fp32 search loops): used to rank tiles by length for the dispatch order (pair_tiles)
+# C3): used to rank tiles by length for the dispatch order (pair_tiles) and to predict a packing's longest tile.  PACK_COST: the 1D
+# kernel of round 3 (one BTPE attempt per bin step; a lone chain is a chain wave: 0.70-0.73 us for the longest ones, which are served
+# first, 0.9-1.2 for the others); PACK_COST_2D: the 2D kernel (round-2 table).
 _PACK_L = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 56, 64)
-_PACK_US = (0.96, 1.30, 1.52, 1.72, 1.87, 1.97, 2.09, 2.20, 2.39, 2.56, 2.74, 2.83, 2.99, 3.13, 3.32, 3.55, 3.67, 3.79, 3.90, 4.05, 4.17, 4.50, 4.81)
+_PACK_US = (0.72, 1.42, 1.66, 1.88, 2.00, 2.08, 2.18, 2.26, 2.41, 2.49, 2.61, 2.68, 2.77, 2.86, 3.02, 3.13, 3.16, 3.17, 3.18, 3.26, 3.32, 3.60, 3.87)
+_PACK_US_2D = (0.96, 1.30, 1.52, 1.72, 1.87, 1.97, 2.09, 2.20, 2.39, 2.56, 2.74, 2.83, 2.99, 3.13, 3.32, 3.55, 3.67, 3.79, 3.90, 4.05, 4.17, 4.50, 4.81)
 PACK_COST = np.interp(np.arange(1, 65), _PACK_L, _PACK_US)
+PACK_COST_2D = np.interp(np.arange(1, 65), _PACK_L, _PACK_US_2D)
 # (c) many-chain regime (more tiles than resident wave slots): 2 x 1024 slots; a SIMD retires ~1.46 lone-wave-seconds of tile
 # time per second (older wave 1.0 + younger ~0.46); a tile may take at most PACK_TAIL of the work-bound run time
 PACK_MAX_RESIDENT = 2048
@@ -351,7 +362,7 @@ def _tiles_from_lanes(lanes, n_act):
     return slot_of, n_tiles
 
 
-def pack_lanes(K_sorted_desc, target_waves, dense=False):
+def pack_lanes(K_sorted_desc, target_waves, dense=False, consts=None, cost=None):
     """Lane packing of sequential chains into 64-wide tiles (one tile = one wave).
 
     ``K_sorted_desc``: steps of each chain, descending.  A chain is one sequential stream, so a wave costs about
@@ -368,12 +379,12 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
         return np.zeros(0, dtype=np.int64), 0
     if dense:
         return _tiles_from_lanes(np.full(n_act, 64, dtype=np.int64), n_act)
-    C0, C1 = PACK_C0, PACK_C1
+    C0, C1, C0_3, C1_3, WAVES3 = consts if consts is not None else (PACK_C0, PACK_C1, PACK3_C0, PACK3_C1, PACK_WAVES3)
 
-    def lanes_for(budget):
-        return np.clip(np.floor((budget / Ks - C0) / C1), 1, 64)
+    def resident(n_waves, C0, C1):
+        def lanes_for(budget):
+            return np.clip(np.floor((budget / Ks - C0) / C1), 1, 64)
 
-    def resident(n_waves):
         lo_b, hi_b = C0 + C1, float(Ks.max()) * (C0 + 64 * C1) * 4.0
         for _ in range(50):
             mid = 0.5 * (lo_b + hi_b)
@@ -383,8 +394,8 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
                 hi_b = mid
         return np.maximum.accumulate(lanes_for(hi_b).astype(np.int64))
 
-    lanes = resident(target_waves)
-    c = PACK_COST
+    lanes = resident(target_waves, C0, C1)
+    c = PACK_COST if cost is None else cost
     # MANY chains (2D pair lists, hundreds of groups): 64-wide tiles no longer fit the resident wave slots, or they fit only
     # because even the longest chains were made 64 wide (a 64-wide step costs 6x a lone chain's, and that tile then runs
     # long after everything else has finished).  There the schedule should be work-bound instead: tiles run in several
@@ -427,14 +438,19 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False):
                      chosen="work-bound" if use_work_bound else "resident")
     if use_work_bound:
         lanes = lanes_w
-    elif target_waves == PACK_WAVES and PACK_WAVES3 > PACK_WAVES:
+    elif target_waves == PACK_WAVES and WAVES3 > PACK_WAVES:
         # A third wave per SIMD (the kernels' 3-wave build, taken above 2048 tiles): narrower tiles for the same chains.  It
         # pays when the longest tile gets shorter -- the waves of this kernel leave ~40 % of the issue slots empty, a third wave
         # fills some -- and costs when the longest chain is already alone in its tile (then only the work grows).  Measured
         # (tools/pack_sweep.py, 2000 vs 2750 tiles): C3 shapes with 250k / 500k / 1M cells 2889 -> 2738, 3162 -> 2993,
-        # 3815 -> 3591 ms (model: longest tile -8 to -10 %); C2 368 -> 391 ms (model: longest tile unchanged).
-        lanes3 = resident(PACK_WAVES3)
-        if float((1.0 / lanes3).sum()) <= 3 * PAIR_SLOTS and float((Ks * c[lanes3 - 1]).max()) <= 0.95 * longest_resident:
+        # 3815 -> 3591 ms (model: longest tile -8 to -10 %); C2 368 -> 391 ms (model: longest tile unchanged).  Round-3 kernel: C3
+        # 3.32-3.38 s with two waves per SIMD (2,018 tiles), 3.24-3.28 s with three (3,071; model -5 %); C2 (bounded by its longest
+        # chain alone in a wave, 0.25 of 0.26 s) stays at two.
+        lanes3, w3 = resident(WAVES3, C0_3, C1_3), WAVES3
+        while _tiles_from_lanes(lanes3, n_act)[1] > 3 * PAIR_SLOTS and w3 > PACK_WAVES:   # (whole tiles: every lane count rounds up)
+            w3 -= 16
+            lanes3 = resident(w3, C0_3, C1_3)
+        if float((1.0 / lanes3).sum()) <= 3 * PAIR_SLOTS and float((Ks * c[lanes3 - 1]).max()) <= 0.97 * longest_resident:
             lanes = lanes3
             PACK_LAST.update(chosen="resident, 3 waves / SIMD", tiles_resident=float((1.0 / lanes3).sum()))
     return _tiles_from_lanes(lanes, n_act)
@@ -464,7 +480,7 @@ PAIR_SLOTS = 1024      # SIMDs: tiles t and t + PAIR_SLOTS share one
 PAIR_TILES = True      # tools only: False = plain longest-first dispatch order
 
 
-def pair_tiles(slot_of, n_tiles, K_of):
+def pair_tiles(slot_of, n_tiles, K_of, cost=None):
     """Dispatch order of the replay tiles.  Two waves share a SIMD and the OLDER one is served first (measured: the
     younger wave runs at ~0.46 of its lone speed until the older retires, tools/replay_balance.py).  Workgroups are handed
     out round-robin, so tile t and tile t + 1024 meet on one SIMD: put the 1024 longest tiles first, longest first, and
@@ -476,7 +492,7 @@ def pair_tiles(slot_of, n_tiles, K_of):
     lanes = np.bincount(tile, minlength=n_tiles)
     kmax = np.zeros(n_tiles)
     np.maximum.at(kmax, tile, np.asarray(K_of, dtype=np.float64))
-    est = kmax * PACK_COST[np.clip(lanes, 1, 64) - 1]
+    est = kmax * (PACK_COST if cost is None else cost)[np.clip(lanes, 1, 64) - 1]
     by_len = np.argsort(-est, kind="stable")
     h = min(PAIR_SLOTS, n_tiles // 2 + n_tiles % 2)
     first, rest = by_len[:h], by_len[h:]
@@ -1046,8 +1062,8 @@ class Bootstrap2D:
         active = (~np.asarray(skip, dtype=bool)) & (self.K >= 1)
         act = np.flatnonzero(active)
         order = act[np.argsort(-self.K[act], kind="stable")]
-        slot_of, n_tiles = pack_lanes(self.K[order], PACK_WAVES if target_waves is None else target_waves)
-        slot_of = pair_tiles(slot_of, n_tiles, self.K[order])
+        slot_of, n_tiles = pack_lanes(self.K[order], PACK_WAVES if target_waves is None else target_waves, consts=PACK2D, cost=PACK_COST_2D)
+        slot_of = pair_tiles(slot_of, n_tiles, self.K[order], cost=PACK_COST_2D)
         self.n_tiles = n_tiles
         pair_slot = np.full(self.n_q, -1, dtype=np.int64)
         pair_slot[order] = slot_of

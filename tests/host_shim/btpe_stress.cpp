@@ -26,9 +26,9 @@ int main(int argc,char**argv){
     npyrng::Pcg64 g0{rng(),rng(),rng(),rng()|1};
     npyrng::Pcg64 a=g0,b=g0;
     #ifdef STRESS_LAZY   // the variant the one-chain-per-wave kernel instantiates (rare-branch set-up kept inside the branches)
-    int32_t yf = npyrng::binomial_btpe_fast<int32_t, true>(a,(int32_t)n,p);
+    int32_t yf = npyrng::binomial_btpe_fast<int32_t, true>(a,(int32_t)n,p,0);
 #else
-    int32_t yf = npyrng::binomial_btpe_fast<int32_t>(a,(int32_t)n,p);
+    int32_t yf = npyrng::binomial_btpe_fast<int32_t>(a,(int32_t)n,p,0);
 #endif
     int32_t ye = npyrng::binomial_btpe<int32_t>(b,(int32_t)n,p);
     done++;

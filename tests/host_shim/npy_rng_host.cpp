@@ -83,6 +83,35 @@ void host_multinomial_fast(const uint64_t st[4], int64_t n, const double *pix, i
   delete[] lq;
 }
 
+// the guarded fast paths with ONE BTPE attempt per call (binomial_pre_capped), the call repeated until the draw is complete: what a
+// lane of the lock-step tile kernel does over consecutive bin steps (csrc/boot.hip: BOOT_BTPE_CAP)
+void host_multinomial_capped(const uint64_t st[4], int64_t n, const double *pix, int d, int B, int64_t *out) {
+  npyrng::Pcg64 g{st[0], st[1], st[2], st[3]};
+  double *pk = new double[d], *lq = new double[d];
+  double rem = 1.0;
+  for (int j = 0; j < d - 1; j++) {
+    pk[j] = pix[j] / rem;
+    lq[j] = npyrng::binomial_lq(pk[j]);
+    rem -= pix[j];
+  }
+  for (int b = 0; b < B; b++) {
+    int64_t *mn = out + (int64_t)b * d;
+    int32_t dn32 = (int32_t)n;
+    for (int j = 0; j < d - 1; j++) {
+      bool pending = true;
+      int32_t w = 0;
+      int cap = 1 + (b + j) % 2;                    // one or two attempts per call
+      while (pending) w = npyrng::binomial_pre_capped<int32_t>(g, pk[j], lq[j], dn32, cap, pending);
+      mn[j] = w;
+      dn32 -= w;
+      if (dn32 <= 0) break;
+    }
+    if (dn32 > 0) mn[d - 1] = dn32;
+  }
+  delete[] pk;
+  delete[] lq;
+}
+
 // the same chain through the RESUMABLE form of the samplers (csrc/npy_rng.h: lane_begin / lane_inv / lane_att / ...), driven the
 // way one lane of the lane-asynchronous tile kernel (csrc/boot.hip: k_boot1d_async) drives it: one phase per pass
 void host_multinomial_async(const uint64_t st[4], int64_t n, const double *pix, int d, int B, int64_t *out) {

@@ -84,7 +84,7 @@ def test_multinomial_random_shapes(shim):
         pv = mult / mult.sum()
         B = 50
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
-        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async", "host_multinomial_async_bf"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_capped", "host_multinomial_async", "host_multinomial_async_bf"):
             got = _multi(shim, 5, n, pv, B, fn)
             np.testing.assert_array_equal(got, ref, err_msg=f"{fn} trial {trial} d={d} n={n}")
 
@@ -93,7 +93,7 @@ def test_multinomial_golden_weights(shim, internals_small):
     it = internals_small
     for k in range(int(it["n_picks"])):
         mult = it[f"p{k}_counts"]
-        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_async", "host_multinomial_async_bf"):
+        for fn in ("host_multinomial", "host_multinomial_pre", "host_multinomial_fast", "host_multinomial_capped", "host_multinomial_async", "host_multinomial_async_bf"):
             got = _multi(shim, 5, int(it[f"p{k}_n_obs"]), mult / mult.sum(), int(it["num_boot"]), fn)
             np.testing.assert_array_equal(got.T, it[f"p{k}_weights"])
 
@@ -117,6 +117,27 @@ def test_guarded_fast_binomial_matches_numpy(shim, n, p):
     np.testing.assert_array_equal(out, ref)
     inv_fb, f_fb = _fallbacks(shim)
     assert inv_fb + f_fb < 0.02 * cnt + 5, (inv_fb, f_fb)          # the fast path really is the common path
+
+
+@pytest.mark.parametrize("which", ["plain", "perturbed"])
+def test_guarded_fast_inversion_small_n_stress(shim, shim_perturbed, which):
+    """The fp32 inversion search on small n, where its recurrence factor (n + 1) s / x - s (one fused multiply-add) cancels towards the end
+    of the support: 4,000 random (n <= 150, n p <= 30) x 300 draws, every draw numpy's; the guard (1.5e-4 on either side of every step of the CDF) sends ~1 % to the exact search."""
+    lib = shim if which == "plain" else shim_perturbed
+    rng = np.random.default_rng(33)
+    cnt = 300
+    out = np.zeros(cnt, dtype=np.int64)
+    _fallbacks(lib)
+    for trial in range(4000):
+        n = int(rng.integers(1, 151))
+        p = float(min(0.5, rng.uniform(0.0, 30.0) / n)) if trial % 4 else float(rng.uniform(0.3, 0.5))
+        if p * n > 30.0:
+            p = 30.0 / n
+        lib.host_binomial_fast(pcg_state(5), ctypes.c_double(p), ctypes.c_int64(n), cnt, out.ctypes.data_as(ctypes.c_void_p))
+        ref = np.random.Generator(np.random.PCG64(5)).binomial(n, p, cnt)
+        np.testing.assert_array_equal(out, ref, err_msg=f"n={n} p={p!r}")
+    inv_fb, f_fb = _fallbacks(lib)
+    assert inv_fb < 0.02 * 4000 * cnt and f_fb == 0, (inv_fb, f_fb)
 
 
 @pytest.mark.parametrize("which", ["plain", "perturbed"])
@@ -147,9 +168,11 @@ def test_resumable_samplers_multinomial_stress(shim, shim_perturbed, which, fn):
     assert draws > 2_500_000 and inv_fb < 1e-2 * draws and f_fb < 5e-3 * draws, (draws, inv_fb, f_fb)
 
 
-def test_guarded_fast_multinomial_stress(shim):
+@pytest.mark.parametrize("fn", ["host_multinomial_fast", "host_multinomial_capped"])
+def test_guarded_fast_multinomial_stress(shim, fn):
     """C3-like chains (48k-cell groups, 60-350 bins, scRNA-like multiplicities) through the guarded fast paths: > 4e6 binomial
-    draws, every weight equal to numpy's; the guards send about 1 draw in 1,000 to the exact arithmetic."""
+    draws, every weight equal to numpy's; the guards send about 1 draw in 1,000 to the exact arithmetic.  ``host_multinomial_capped``:
+    one or two BTPE attempts per call, the call repeated until the draw is complete (the tile kernel's form)."""
     rng = np.random.default_rng(11)
     draws = 0
     _fallbacks(shim)
@@ -163,7 +186,7 @@ def test_guarded_fast_multinomial_stress(shim):
         pv = mult / mult.sum()
         B = 500
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=B)
-        got = _multi(shim, 5, n, pv, B, "host_multinomial_fast")
+        got = _multi(shim, 5, n, pv, B, fn)
         np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial} d={d} n={n}")
         draws += (d - 1) * B
     inv_fb, f_fb = _fallbacks(shim)
@@ -201,5 +224,6 @@ def test_guarded_fast_multinomial_with_perturbed_primitives(shim_perturbed):
         n = int(mult.sum())
         pv = mult / mult.sum()
         ref = np.random.Generator(np.random.PCG64(5)).multinomial(n, pv, size=300)
-        got = _multi(shim_perturbed, 5, n, pv, 300, "host_multinomial_fast")
-        np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial}")
+        for fn in ("host_multinomial_fast", "host_multinomial_capped"):
+            got = _multi(shim_perturbed, 5, n, pv, 300, fn)
+            np.testing.assert_array_equal(got, ref, err_msg=f"{fn} trial {trial}")

@@ -115,8 +115,20 @@ def main():
                     ["retire/restart", "start (both set-ups)", "inversion segment + attempt", "attempt outside the triangle", "explicit", "squeeze", "exact redo"], per)) + f"; sum {per.sum():.0f}", flush=True)
         if bs.n_tiles:
             wt = raw[: bs.n_tiles * 4].reshape(-1, 4)
-            dur = (wt[:, 1] - wt[:, 0]) / 1e8
-            print(f"   tile kernel: span {(wt[:, 1].max() - wt[:, 0].min()) / 1e8:.3f} s, longest wave {dur.max():.3f} s, sum of wave time {dur.sum():.1f} s", flush=True)
+            lanes = (bs.slot_K.reshape(bs.n_tiles, 64) > 0).sum(axis=1)
+            real = lanes > 0                      # (tiles whose only chain runs as a chain wave leave no record here)
+            dur = ((wt[:, 1] - wt[:, 0]) / 1e8)[real]
+            kmax = np.diff(bs.tile_ptr)[real]
+            ln = lanes[real]
+            print(f"   tile kernel: {real.sum()} lock-step tiles, span {(wt[real, 1].max() - wt[real, 0].min()) / 1e8:.3f} s, longest wave {dur.max():.3f} s, "
+                  f"sum of wave time {dur.sum():.1f} s", flush=True)
+            for lo, hi in ((2, 8), (8, 24), (24, 48), (48, 65)):
+                sel = (ln >= lo) & (ln < hi)
+                if sel.any():
+                    print(f"     tiles of [{lo},{hi}) lanes: {sel.sum()} (bins {kmax[sel].min()}..{kmax[sel].max()}): us per (nominal) step median "
+                          f"{np.median(dur[sel] / (kmax[sel] * B)) * 1e6:.2f}; wave s median {np.median(dur[sel]):.3f} max {dur[sel].max():.3f}", flush=True)
+            top = np.argsort(-dur)[:6]
+            print("     longest tiles (s, lanes, bins): " + ", ".join(f"({dur[i]:.3f}, {ln[i]}, {kmax[i]})" for i in top), flush=True)
 
 
 if __name__ == "__main__":

@@ -33,6 +33,7 @@ timer = ctypes.c_void_p(); _lib.call("mm_timer_create", ctypes.byref(timer)); s 
 for combo in combos:
     c0, c1, waves = combo[:3]
     engine.PACK_C0, engine.PACK_C1, engine.PACK_WAVES = float(c0), float(c1), int(waves)
+    engine.PACK3_C0, engine.PACK3_C1 = float(c0), float(c1)
     engine.PACK_MAX_RESIDENT = int(combo[3]) if len(combo) > 3 else 2048
     engine.PAIR_SLOTS = int(combo[4]) if len(combo) > 4 else 1024
     engine.PACK_WAVES3 = int(combo[5]) if len(combo) > 5 else 2750
