@@ -325,8 +325,23 @@ NPY_HD float f_stirling(float x) {            // btpe_stirling in fp32: ~1/(12 x
   return (13680.0f - (462.0f - (132.0f - (99.0f - 140.0f * ix2) * ix2) * ix2) * ix2) * ix * (1.0f / 166320.0f);
 }
 
+// Guard of the fp32 inversion search, absolute, on U - CDF(X): G = G0 + GA |n log q| + GX X (+ GS for n < 128), four times this
+// bound of the fp32 evaluation's error after X steps:
+//   q^n = exp(n log q): the argument (<= 42 in magnitude) is rounded to fp32 and multiplied by log2(e) -> relative 1.5e-7 |arg| + 3e-7;
+//   every step multiplies px by a factor of relative error <= 4e-7 (s = p/q through v_rcp_f32, the fused multiply-add; for n < 128 the
+//   cancellation in (n + 1) s / x - s adds at most 1e-5 in all, GS) and subtracts it from U with a rounding of <= 6e-8:
+//   |error of U_X, of px_X| <= 1e-7 (X + 1) + (1.5e-7 |arg| + 3e-7 + 4e-7 X) * CDF.
+// (Round 2 used the constant 1.5e-4 = the bound at X = 60: a search that stops at X <= 3 -- most of them -- was sent to the exact
+// fp64 search 30 times more often than its own error warrants, and in a 64-wide tile every such draw costs the whole wave a
+// sequential fp64 search with a division per step.)
 #ifndef NPY_INV_GUARD
-#define NPY_INV_GUARD 1.5e-4f // absolute, on U - CDF.  fp32 error of exp + recurrence + running subtraction: worst-case bound 4e-5 for X <= 60, largest seen in 2e7 random draws 8e-6
+#define NPY_INV_GUARD 1.5e-4f // the constant guard (the bound at X = 60): still used by the resumable forms below (lane_inv_finish, lane_inv_att_bf)
+#endif
+#ifndef NPY_INV_G0
+#define NPY_INV_G0 2.4e-6f
+#define NPY_INV_GA 8e-7f
+#define NPY_INV_GX 2.4e-6f
+#define NPY_INV_GS 1e-5f
 #endif
 #ifndef NPY_BTPE_LOGF
 #define NPY_BTPE_LOGF 1       // binomial_btpe_fast: the explicit-product acceptance test through the closed log form where that is accurate
@@ -343,7 +358,8 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
   float nf = (float)n, pf = (float)p;
   float qf = 1.0f - pf;                       // p <= 0.5
   float s = pf * f_rcp(qf);
-  float qn = f_exp((float)((double)n * lq));  // n*lq >= -1.39 n p >= about -42 for n*p <= 30 (p <= 0.5): inside the fp32 range
+  const float argf = (float)((double)n * lq); // n*lq >= -1.39 n p >= about -42 for n*p <= 30 (p <= 0.5): inside the fp32 range
+  float qn = f_exp(argf);
   float Uf = (float)U, px = qn;
   int32_t X = 0;
 #ifdef NPY_ABLATE_INV_LOOP  // timing experiments only: wrong results
@@ -355,7 +371,7 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
   // the bound (a square root) is only worked out by searches that get that far.
   // the factor (n + 1 - x) s / x of the recurrence as one fused multiply-add, (n + 1) s * (1/x) - s (1/x a literal): its
   // cancellation costs at most (n + 1)/(n + 1 - x) ulps of the factor, i.e. something only for n < ~120 near the end of the support,
-  // where it adds < 1e-5 to the absolute error of the running sum (bound in NPY_INV_GUARD's comment: 4e-5; the guard is 1.5e-4)
+  // where it adds < 1e-5 to the absolute error of the running sum (NPY_INV_GS in the guard)
   const float a_s = (nf + 1.0f) * s;
   const int32_t cap9 = n < (Int)9 ? (int32_t)n : 9;
 #pragma unroll
@@ -380,7 +396,8 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
       px = px * __builtin_fmaf(a_s, 1.0f / (float)it, -s);
     }
   }
-  bool ok = (px - Uf > NPY_INV_GUARD) && (X == 0 || Uf > NPY_INV_GUARD);   // also false when the search stopped at a cap
+  const float G = (NPY_INV_G0 + (n < (Int)128 ? NPY_INV_GS : 0.0f)) + NPY_INV_GA * fabsf(argf) + NPY_INV_GX * (float)X;
+  bool ok = (px - Uf > G) && (X == 0 || Uf > G);   // also false when the search stopped at a cap
   return ok ? X : -1;
 }
 
