@@ -840,6 +840,9 @@ __global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ 
 // covariance and the two variances (bootstrap.py:141-155, estimator.py:214-218, :171-174) are folded
 // into the correlation exactly as estimator._corr_from_cov does (:281-292: 5.0 sentinel where a variance
 // is <= 0, then clip to [-1, 1]).  Writes corr_b to out[row*ld + 1 + b].
+#ifndef BOOT2D_BTPE_CAP
+#define BOOT2D_BTPE_CAP 0
+#endif
 template <int MINW, bool FAST>
 __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v1_, const double *__restrict__ v2_,
@@ -873,32 +876,52 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
     double A1 = 0.0, A2 = 0.0, MX = 0.0, Q1 = 0.0, Q2 = 0.0;
     int32_t dn = n;
     bool live = true;
-    for (int k = 0; k < kmax; k++) {
-      int kn = k + 1 < kmax ? k + 1 : 0;
+    // this lane's bin, as in k_boot1d_replay -- but BOOT2D_BTPE_CAP is 0: measured on configs[3]'s share (250 x 2000 pairs, 335 bins
+    // per chain on average, 64-wide tiles in several rounds) one attempt per step takes 29.2 s against 16.8 s: the steps of this
+    // kernel are short (small inversion searches), and lanes that fall behind by different amounts turn the six coalesced 512-B
+    // operand rows of a step into up to 64 separate lines each.
+    int kl = 0;
+    for (;;) {
+      const bool act = run && kl < K;
+      const uint64_t act_mask = __ballot(act);
+      if (act_mask == 0) break;
+      const int cap = (BOOT2D_BTPE_CAP > 0 && __popcll(act_mask) > BOOT_TAIL_LANES) ? BOOT2D_BTPE_CAP : 0;
+      int kn = kl + 1 < K ? kl + 1 : 0;
       int64_t on = obase + (int64_t)kn * 64;
       double n_pk = pk_[on], n_lq = lq_[on], n_x1 = v1_[on], n_x2 = v2_[on], n_a = a[on], n_b = b[on];
-      if (run && k < K) {
+      bool adv = false;
+      if (act) {
         int32_t w;
-        if (k < K - 1) {
+        bool pending = false;
+        if (kl < K - 1) {
           w = 0;
           if (live) {
-            w = npyrng::binomial_pre<int32_t, FAST>(g, c_pk, c_lq, dn);
-            dn -= w;
-            if (dn <= 0) live = false;
+            if constexpr (FAST) w = npyrng::binomial_pre_capped<int32_t>(g, c_pk, c_lq, dn, cap, pending);
+            else w = npyrng::binomial_pre<int32_t, false>(g, c_pk, c_lq, dn);
+            if (!pending) {
+              dn -= w;
+              if (dn <= 0) live = false;
+            }
           }
         } else {
           w = dn > 0 ? dn : 0;
         }
-        if (w != 0) {
-          double wd = (double)w, x1 = c_x1, x2 = c_x2, aa = c_a, bb = c_b;
-          A1 += (x1 * wd) * aa;
-          A2 += (x2 * wd) * aa;
-          MX += ((x1 * x2) * wd) * bb;
-          Q1 += ((x1 * x1) * wd) * bb - ((omq * x1) * wd) * bb;
-          Q2 += ((x2 * x2) * wd) * bb - ((omq * x2) * wd) * bb;
+        if (!pending) {
+          if (w != 0) {
+            double wd = (double)w, x1 = c_x1, x2 = c_x2, aa = c_a, bb = c_b;
+            A1 += (x1 * wd) * aa;
+            A2 += (x2 * wd) * aa;
+            MX += ((x1 * x2) * wd) * bb;
+            Q1 += ((x1 * x1) * wd) * bb - ((omq * x1) * wd) * bb;
+            Q2 += ((x2 * x2) * wd) * bb - ((omq * x2) * wd) * bb;
+          }
+          adv = true;
         }
       }
-      c_pk = n_pk; c_lq = n_lq; c_x1 = n_x1; c_x2 = n_x2; c_a = n_a; c_b = n_b;
+      if (adv) {
+        kl++;
+        c_pk = n_pk; c_lq = n_lq; c_x1 = n_x1; c_x2 = n_x2; c_a = n_a; c_b = n_b;
+      }
     }
     if (run) {
       double m1 = A1 / nobs, m2 = A2 / nobs;

@@ -42,6 +42,8 @@ def main():
     hist = np.histogram(K, bins=edges)[0]
     print("K histogram:", ", ".join(f"[{a},{b}) {c}" for a, b, c in zip(edges[:-1], edges[1:], hist)), flush=True)
     r = np.random.default_rng(0).random((2, bs.n_pairs))
+    if os.environ.get("MM_ROWS_MOD"):       # timing experiment (WRONG results): tiles read their operand rows out of a cache-resident region
+        _lib.call("mm_debug_replay_rows_mod", int(os.environ["MM_ROWS_MOD"]))
     timer, ms = ctypes.c_void_p(), ctypes.c_float()
     _lib.call("mm_timer_create", ctypes.byref(timer))
     buf = torch.zeros((1 << 20,), dtype=torch.int64, device="cuda")
