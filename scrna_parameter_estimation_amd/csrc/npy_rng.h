@@ -520,7 +520,30 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r, int cap NPY_ST_PARAM) {  
     // Stirling-corrected log form otherwise.  The log form IS log F (up to the truncation of the Stirling series, < 1e-9 for arguments
     // >= 8), so the explicit case can take it too -- no loop of up to 64 factors that every lane of a wave waits for: v <= F iff
     // log v <= bound.  The product is kept for small arguments and large log1p arguments.
-    const bool expl = !((k > 20) && ((double)k < nrq / 2.0 - 1));
+    // Before any of that, the squeeze: t - rho <= log(f(y)/f(m)) <= t + rho holds for EVERY k < nrq/2 - 1 (Kachitvichyanukul & Schmeiser's
+    // bounds; numpy consults them for k > 20 only because the product is cheap below -- checked on 2e7 (n, r, k), tests/test_npy_rng_host.py).
+    // For numpy's squeeze candidates it IS numpy's decision; for its explicit candidates it is a sound shortcut to the same decision
+    // (v <= F): nine candidates in ten are settled here, and the logarithms, reciprocals and Stirling terms below are worked out in
+    // the bin steps where some lane of the wave is left undecided, not in all of them.
+    const bool sq_ok = (double)k < nrq / 2.0 - 1;
+    const bool expl = !((k > 20) && sq_ok);
+    if (v < 1e-11) {
+      if (v > -1e-11) return -1;
+      return y;       // numpy: v <= 0 < F (explicit case); log of a negative number is NaN and every comparison fails (squeeze case): accepted
+    }
+    float A = f_log((float)v);
+    if (sq_ok) {
+      const float rnrq = f_rcp((float)NPY_KEEP(tk, nrq, r));
+      float kf = (float)k;
+      float rho = (kf * rnrq) * ((kf * (kf * 0.333333333f + 0.625f) + 0.16666666666666666f) * rnrq + 0.5f);
+      float t = -(kf * kf) * 0.5f * rnrq;
+      float gs = 1e-5f * (1.0f + fabsf(A)) + 6e-6f * (fabsf(t) + rho);
+      float lo_ = t - rho, hi_ = t + rho;
+      NPY_ST(5);
+      if (A < lo_ - gs) return y;
+      if (A > hi_ + gs) continue;
+      if (!expl && (A < lo_ + gs || A > hi_ - gs)) return -1;      // numpy's own decision changes at lo / hi: too close to tell
+    }
     float yf1 = (float)y + 1.0f;                                        // x1
     float wf = (float)(n - y) + 1.0f;                                   // w
     float d1 = (float)(m - y) * f_rcp(yf1);                             // f1/x1 - 1 = (m - y)/(y + 1)
@@ -537,24 +560,7 @@ NPY_HD Int binomial_btpe_fast(Gen &g, Int n, double r, int cap NPY_ST_PARAM) {  
       if (dec == 0) continue;
       return y;
     }
-    if (v < 1e-11) {
-      if (v > -1e-11) return -1;
-      return y;       // numpy: v <= 0 < F (explicit case); log of a negative number is NaN and every comparison fails (squeeze case): accepted
-    }
-    float A = f_log((float)v);
-    if (!expl) {      // squeeze
-      const float rnrq = f_rcp((float)NPY_KEEP(tk, nrq, r));
-      float kf = (float)k;
-      float rho = (kf * rnrq) * ((kf * (kf * 0.333333333f + 0.625f) + 0.16666666666666666f) * rnrq + 0.5f);
-      float t = -(kf * kf) * 0.5f * rnrq;
-      float gs = 1e-5f * (1.0f + fabsf(A)) + 6e-6f * (fabsf(t) + rho);
-      float lo_ = t - rho, hi_ = t + rho;
-      NPY_ST(5);
-      if (A < lo_ - gs) return y;
-      if (A > hi_ + gs) continue;
-      if (A < lo_ + gs || A > hi_ - gs) return -1;
-      if (!(NPY_BTPE_ANYD ? sane_d : small_d)) return -1;
-    }
+    if (!expl && !(NPY_BTPE_ANYD ? sane_d : small_d)) return -1;
     // (a bin with n r of 30-100 and a candidate 21+ away from the mode has |d| > 0.35: the fp32 logarithm then, with its absolute
     // error in the guard -- these were 80 % of the draws that went to the exact redo)
     const float c1 = (float)xm, c2 = (float)(n - m) + 0.5f, c3 = (float)(y - m);

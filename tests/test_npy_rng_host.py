@@ -227,3 +227,42 @@ def test_guarded_fast_multinomial_with_perturbed_primitives(shim_perturbed):
         for fn in ("host_multinomial_fast", "host_multinomial_capped"):
             got = _multi(shim_perturbed, 5, n, pv, 300, fn)
             np.testing.assert_array_equal(got, ref, err_msg=f"{fn} trial {trial}")
+
+
+def test_btpe_squeeze_bounds_hold_for_every_k_below_half_nrq():
+    """binomial_btpe_fast settles numpy's EXPLICIT candidates (k <= 20) through the squeeze bounds too, which numpy itself consults only
+    for k > 20: t - rho <= log(f(y)/f(m)) <= t + rho must therefore hold for every 1 <= k < nrq/2 - 1 (Kachitvichyanukul & Schmeiser 1988,
+    step 5.2; the reference reaches numpy's copy of it through Generator.multinomial, memento/bootstrap.py:103).  Checked in fp64
+    against the explicit product on ~4e6 (n, p, k): n p > 30, p in [1e-7, 0.5], n up to 2^31, both sides of the mode."""
+    rng = np.random.default_rng(0)
+    checked = 0
+    worst = np.inf
+    for trial in range(40000):
+        p = float(np.exp(rng.uniform(np.log(1e-7), np.log(0.5))))
+        nmin = int(30 / p) + 2
+        n = int(min(2 ** 31 - 2, nmin * np.exp(rng.uniform(0, np.log(2000))))) if trial % 3 else nmin + int(rng.integers(0, 50))
+        if n * p <= 30:
+            continue
+        q = 1 - p
+        nrq = n * p * q
+        m = int(np.floor(n * p + p))
+        kmax = int(min(80, np.ceil(nrq / 2 - 1) - 1))
+        if kmax < 1:
+            continue
+        s_, aa = p / q, (p / q) * (n + 1)
+        for sign in (1, -1):
+            i = np.arange(m + 1, m + kmax + 1) if sign > 0 else np.arange(m, max(0, m - kmax), -1)
+            if sign > 0:
+                i = i[i <= n]
+            if len(i) == 0:
+                continue
+            log_f = np.cumsum(np.log(aa / i - s_)) * sign            # log(f(m + sign k) / f(m)), k = 1 .. len(i)
+            kf = np.arange(1, len(i) + 1, dtype=np.float64)
+            rho = (kf / nrq) * ((kf * (kf / 3.0 + 0.625) + 0.1666666666666) / nrq + 0.5)
+            t = -kf * kf / (2 * nrq)
+            slack = np.minimum(log_f - (t - rho), (t + rho) - log_f)
+            assert (slack >= -1e-13 * (1 + np.abs(log_f))).all(), (n, p, sign, int(np.argmin(slack)) + 1)
+            worst = min(worst, float((slack / rho).min()))
+            checked += len(i)
+    assert checked > 3_000_000
+    print(f"\n{checked} (n, p, k): smallest slack {worst:.2e} of rho")
