@@ -32,8 +32,10 @@ PACK_WAVES = 2000
 # 220 / 3: 267-270 ms against 283).  The 2D kernel keeps the constants it was tuned with.
 PACK3_C0 = 260.0
 PACK3_C1 = 2.2
-PACK_WAVES3 = 3050
+PACK_WAVES3 = 4000
 PACK2D = (220.0, 3.0, 220.0, 3.0, 2750)
+PACK_OVERSUB = 1024      # tiles the three-waves-per-SIMD packing may have beyond the 3 x 1024 resident slots: the shortest ones, dispatched last, start as
+                         # the first workgroups retire (C3, tools/pack_sweep.py: 3.18 s with 3,071 tiles, 3.07 / 3.02 / 3.00 / 3.07 / 3.57 s with 3,300 / 3,600 / 4,000 / 4,500 / 5,000)
 # (b) measured time of one bin step of a wave of L chains running as the OLDER wave of its SIMD, us (tools/replay_balance.py,
 # C3): used to rank tiles by length for the dispatch order (pair_tiles) and to predict a packing's longest tile.  PACK_COST: the 1D
 # kernel of round 3 (one BTPE attempt per bin step; a lone chain is a chain wave: 0.70-0.73 us for the longest ones, which are served
@@ -447,10 +449,10 @@ def pack_lanes(K_sorted_desc, target_waves, dense=False, consts=None, cost=None)
         # 3.32-3.38 s with two waves per SIMD (2,018 tiles), 3.24-3.28 s with three (3,071; model -5 %); C2 (bounded by its longest
         # chain alone in a wave, 0.25 of 0.26 s) stays at two.
         lanes3, w3 = resident(WAVES3, C0_3, C1_3), WAVES3
-        while _tiles_from_lanes(lanes3, n_act)[1] > 3 * PAIR_SLOTS and w3 > PACK_WAVES:   # (whole tiles: every lane count rounds up)
+        while _tiles_from_lanes(lanes3, n_act)[1] > 3 * PAIR_SLOTS + PACK_OVERSUB and w3 > PACK_WAVES:   # (whole tiles: every lane count rounds up)
             w3 -= 16
             lanes3 = resident(w3, C0_3, C1_3)
-        if float((1.0 / lanes3).sum()) <= 3 * PAIR_SLOTS and float((Ks * c[lanes3 - 1]).max()) <= 0.97 * longest_resident:
+        if float((1.0 / lanes3).sum()) <= 3 * PAIR_SLOTS + PACK_OVERSUB and float((Ks * c[lanes3 - 1]).max()) <= 0.97 * longest_resident:
             lanes = lanes3
             PACK_LAST.update(chosen="resident, 3 waves / SIMD", tiles_resident=float((1.0 / lanes3).sum()))
     return _tiles_from_lanes(lanes, n_act)

@@ -352,10 +352,10 @@ def test_pack_and_pair_tiles_are_a_valid_schedule():
     assert cost.max() <= max(Kb[0] * engine.PACK_COST[0], engine.PACK_TAIL * cost.sum() / engine.PACK_RATE) * 1.001
     assert len(np.unique(engine.pair_tiles(sb, nb, Kb))) == len(Kb)
     # a heavy head of long chains that 2,000 tiles cannot give lanes of their own (BASELINE configs[2]'s shape): narrower tiles in
-    # up to three waves per SIMD shorten the longest tile, and the packer takes them; every chain still has exactly one slot
+    # up to three waves per SIMD (plus the late starters of PACK_OVERSUB) shorten the longest tile, and the packer takes them; every chain still has exactly one slot
     Kc = np.sort(np.concatenate([rng.integers(250, 351, size=600), np.clip(rng.lognormal(np.log(70), 0.45, 43_000), 2, 249).astype(int)]))[::-1]
     sc, nc = engine.pack_lanes(Kc, engine.PACK_WAVES)
-    assert engine.PACK_LAST["chosen"].startswith("resident, 3 waves") and 2048 < nc <= 3 * engine.PAIR_SLOTS
+    assert engine.PACK_LAST["chosen"].startswith("resident, 3 waves") and 2048 < nc <= 3 * engine.PAIR_SLOTS + engine.PACK_OVERSUB
     assert len(np.unique(sc)) == len(Kc) and len(np.unique(engine.pair_tiles(sc, nc, Kc))) == len(Kc)
     lc = np.bincount(sc // 64, minlength=nc)
     kc = np.zeros(nc)

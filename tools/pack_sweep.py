@@ -1,6 +1,6 @@
 """Sweep of the replay kernel's lane-packing constants (engine.PACK_C0 / PACK_C1 / PACK_WAVES) on one shape, in ONE process.
 These are module attributes the tools set directly; the product path reads no environment variable.
-usage: python tools/pack_sweep.py [config=C3 | C3@cells[@num_boot]] "c0,c1,waves[,max_resident[,pair_slots[,waves3]]]" ..."""
+usage: python tools/pack_sweep.py [config=C3 | C3@cells[@num_boot]] "c0,c1,waves[,max_resident[,pair_slots[,waves3[,oversubscription]]]]" ..."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch, scipy.sparse as sp
@@ -37,6 +37,7 @@ for combo in combos:
     engine.PACK_MAX_RESIDENT = int(combo[3]) if len(combo) > 3 else 2048
     engine.PAIR_SLOTS = int(combo[4]) if len(combo) > 4 else 1024
     engine.PACK_WAVES3 = int(combo[5]) if len(combo) > 5 else 2750
+    engine.PACK_OVERSUB = int(combo[6]) if len(combo) > 6 else 0
     _lib.call("mm_timer_begin", timer, s)
     bs.run(skip, r[0], r[1], m["mv_regressor"]["all"], fill_mode=1)
     _lib.call("mm_timer_end", timer, s)
