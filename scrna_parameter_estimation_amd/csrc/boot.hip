@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
 #ifdef BOOT_STAMPS
   uint64_t stamp_inv = 0, stamp_btpe = 0, stamp_t0 = __builtin_amdgcn_s_memtime();
   uint64_t stamp_fastcall = 0;                       // wave time inside the fast BTPE call (the rest of stamp_btpe is the exact redo)
+  uint64_t stamp_iters = 0, stamp_tail_iters = 0;    // bin steps the wave really made (retries included) / of them with only stragglers left
   uint64_t cnt_bt = 0, cnt_fb = 0;                   // BTPE draws of this lane / of them redone in the exact arithmetic
   uint64_t stamp_bt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // inside the fast BTPE: set-up | uniforms | regions | floor + k | explicit product | squeeze | Stirling
 #endif
@@ -241,6 +242,10 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
       const bool act = run && kl < K;
       const uint64_t act_mask = __ballot(act);
       if (act_mask == 0) break;
+#ifdef BOOT_STAMPS
+      stamp_iters++;
+      if (__popcll(act_mask) <= BOOT_TAIL_LANES) stamp_tail_iters++;
+#endif
       const int cap = (BOOT_BTPE_CAP > 0 && __popcll(act_mask) > BOOT_TAIL_LANES) ? BOOT_BTPE_CAP : 0;
       int kn = kl + 1 < K ? kl + 1 : 0;
       int64_t on = obase + (int64_t)kn * 64;
@@ -280,8 +285,13 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
               if (bt && X == -2) {
                 pending = true;
                 cnt_bt--;
-              } else if (bt && X < 0) {
+#ifdef STAMP_RETRY       // (the second counter then counts retried attempts instead of exact redos)
                 cnt_fb++;
+#endif
+              } else if (bt && X < 0) {
+#ifndef STAMP_RETRY
+                cnt_fb++;
+#endif
                 g.rewind(saved);
                 X = npyrng::binomial_btpe<int32_t>(g, dn, p);
               }
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_replay(const double *__res
   }
   if (wave_clock && lane == 0) wave_clock[(n_tiles + tile) * 8 + 7] = (int64_t)((cnt_fb << 40) | cnt_bt);
   if (wave_clock && lane == 0) {  // shader-clock cycles: total, inside the inversion sampler, inside BTPE (wave_clock slots 2, 3 reused)
-    wave_clock[tile * 4 + 0] = t_start;
+    wave_clock[tile * 4 + 0] = (int64_t)((stamp_tail_iters << 40) | stamp_iters);
     wave_clock[tile * 4 + 1] = (int64_t)(__builtin_amdgcn_s_memtime() - stamp_t0);
     wave_clock[tile * 4 + 2] = (int64_t)stamp_inv;
     wave_clock[tile * 4 + 3] = (int64_t)stamp_btpe;

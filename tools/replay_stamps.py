@@ -39,11 +39,14 @@ lanes = (bs.slot_K.reshape(nt, 64) > 0).sum(axis=1)
 steps = np.diff(bs.tile_ptr) * B
 tot, inv, bt = wc[:, 1], wc[:, 2], wc[:, 3]
 print(f"{name}: tiles {nt}; cycles per wave-step by tile width (total | inversion sampler | BTPE | rest):")
+iters = (raw[: nt * 4].reshape(-1, 4)[:, 0] & ((1 << 40) - 1)).astype(np.float64)      # bin steps really made (a rejected BTPE attempt is retried in the next)
+tail = (raw[: nt * 4].reshape(-1, 4)[:, 0] >> 40).astype(np.float64)                  # ... of them with only stragglers left in the replicate
 for lo, hi in ((1, 2), (2, 8), (8, 24), (24, 48), (48, 65)):
     sel = (lanes >= lo) & (lanes < hi)
     if sel.any():
         t, i, b = (tot[sel] / steps[sel]).mean(), (inv[sel] / steps[sel]).mean(), (bt[sel] / steps[sel]).mean()
-        print(f"  lanes [{lo},{hi}): {sel.sum():5d} waves  {t:8.0f} | {i:7.0f} ({i / t:.0%}) | {b:7.0f} ({b / t:.0%}) | {t - i - b:7.0f} ({(t - i - b) / t:.0%})")
+        print(f"  lanes [{lo},{hi}): {sel.sum():5d} waves  {t:8.0f} | {i:7.0f} ({i / t:.0%}) | {b:7.0f} ({b / t:.0%}) | {t - i - b:7.0f} ({(t - i - b) / t:.0%})"
+              f"   steps made / nominal {(iters[sel] / steps[sel]).mean():.3f} (straggler steps {(tail[sel] / steps[sel]).mean():.3f})")
 names = ["set-up", "2 uniforms", "regions", "floor + k", "explicit product", "squeeze", "WHOLE fast call (wave time)"]
 for lo, hi in ((1, 2), (48, 65)):
     sel = (lanes >= lo) & (lanes < hi)
