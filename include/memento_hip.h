@@ -234,6 +234,16 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
                                                uniforms from this table at its own position instead of stepping PCG64 */,
                      int64_t stream_len, int32_t *d_stream_overflow /* set to 1 if a chain ran past the table: redo without it */,
                      void *stream);
+/* K6+K7, FREE-RUNNING tiles (memento/bootstrap.py:97-110, estimator.py:171-174; the launch the timed path uses): slot s = 64 * tile + lane
+ * runs the chain whose 8-double operand records (mm_bins_order, MM_CHAIN_SLOT pairs) are [d_slot_rec[s], d_slot_rec[s] + d_slot_K[s]) of
+ * d_recs; d_slot_rec[s] < 0 or d_slot_K[s] <= 0 = unused lane.  The lanes of a tile share the instruction stream only: a BTPE draw makes
+ * one attempt per bin step and a rejected lane retries in the next, a lane that finishes a replicate starts its next one at once.  Same
+ * draws, replicate means and variances as mm_boot1d_replay, bit for bit.  ``chains`` as there (tiles that are one-wave-per-chain chains).
+ * d_w_dump (optional): int32 weights [slot][k][b], stride kmax_dump. */
+int mm_boot1d_free(const double *d_recs, const int64_t *d_slot_rec, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
+                   const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot, int32_t mean_only,
+                   int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, const mm_chain_tiles *chains,
+                   void *stream);
 /* d_out[i] = the (i + 1)-th uniform of Generator(PCG64(state)).random(): the ONE stream every chain of a launch replays
  * (memento/bootstrap.py:102 seeds PCG64(5) per pair), produced once by lane-parallel jump-ahead. */
 int mm_pcg64_stream(const uint64_t pcg_state[4], int64_t n, double *d_out, void *stream);

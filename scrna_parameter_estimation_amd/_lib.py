@@ -63,6 +63,8 @@ _SIGS = {
     "mm_bins_order": ([c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 13, ctypes.c_int),
     "mm_boot1d_replay": ([c_void_p] * 6 + [c_int64] + [c_void_p] * 4 + [ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
                          c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "mm_boot1d_free": ([c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
+                       c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "mm_pcg64_stream": ([ctypes.POINTER(c_uint64), c_int64, c_void_p, c_void_p], ctypes.c_int),
     "mm_boot1d_chain": ([c_void_p] * 6 + [c_int64, c_void_p, ctypes.POINTER(c_uint64), c_int32, c_int32, c_int64,
                         c_void_p, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),

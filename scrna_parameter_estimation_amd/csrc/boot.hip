@@ -846,6 +846,167 @@ __global__ __launch_bounds__(256) void k_boot1d_fast(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// FREE-RUNNING tile kernel: one lane = one chain, the lanes of a wave share the instruction stream and nothing else.  As in
+// k_boot1d_replay a BTPE draw makes BOOT_BTPE_CAP attempt(s) per bin step and a rejected lane retries in the next step -- but here a
+// lane that finishes a replicate starts its next one at once instead of waiting for the slowest lane of its wave (in-kernel stamps of
+// k_boot1d_replay: a 64-wide tile makes 1.23 bin steps per nominal step, 1.095 is the lanes' average), so every lane carries its own
+// replicate index as well.  The lanes drift apart without bound, and operand ROWS shared by the wave (one coalesced 512-B row per plane
+// and step) would turn into 64 separate lines per plane: the operands are therefore the chain's own 8-double RECORDS (mm_bins_order,
+// MM_CHAIN_SLOT: pk, lq, count, 1/sf, 1/sf^2, one 64-B half line per bin, the form chain_body reads), fetched one bin ahead.
+// Same samplers, same arithmetic per draw, same accumulation order per replicate: the replicate moments are those of
+// k_boot1d_replay bit for bit.  A tile flagged in ca.tile_chain is a chain of the one-wave-per-chain form, as there.
+template <int MINW, bool FAST>
+__global__ __launch_bounds__(256, MINW) void k_boot1d_free(const double *__restrict__ recs, const int64_t *__restrict__ slot_rec,
+                                                           int64_t n_tiles, const int32_t *__restrict__ slot_K,
+                                                           const double *__restrict__ slot_nobs, const double *__restrict__ slot_omq,
+                                                           const int64_t *__restrict__ slot_row, uint64_t st0, uint64_t st1, uint64_t st2,
+                                                           uint64_t st3, int32_t num_boot, int32_t mean_only, int64_t ld,
+                                                           double *__restrict__ out_mean, double *__restrict__ out_var,
+                                                           int32_t *__restrict__ w_dump, int32_t kmax_dump,
+                                                           int64_t *__restrict__ wave_clock, ChainArgs ca) {
+  int lane = mm_lane();
+  int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (tile >= n_tiles) return;
+  if (ca.tile_chain) {
+    int cidx = __builtin_amdgcn_readfirstlane(ca.tile_chain[tile]);
+    if (cidx >= 0) {
+      if (tile * 2 < n_tiles) __builtin_amdgcn_s_setprio(BOOT_SETPRIO);
+      chain_body<FAST>(ca, (int64_t)cidx, lane, st0, st1, num_boot, mean_only, ld, out_mean, out_var,
+                       wave_clock ? wave_clock + MM_CHAIN_CLOCK_OFF : nullptr);
+      return;
+    }
+  }
+  int64_t t_start = wave_clock ? (int64_t)wall_clock64() : 0;
+  if (tile * 2 < n_tiles) __builtin_amdgcn_s_setprio(BOOT_SETPRIO);
+  int64_t slot = tile * 64 + lane;
+  int K = slot_K[slot];
+  int64_t row = slot_row[slot];
+  int64_t rec0 = slot_rec[slot];
+  if (K <= 0 || row < 0 || rec0 < 0) K = 0;  // unused lane
+  double nobs = slot_nobs[slot];
+  double omq = slot_omq[slot];
+  int32_t n = (int32_t)nobs;
+  double *om = out_mean + row * ld + 1;
+  double *ov = out_var + row * ld + 1;
+  if (K == 1) {  // bootstrap.py:97-98: a single bin -> all-NaN replicates
+    for (int r = 0; r < num_boot; r++) {
+      om[r] = NAN;
+      ov[r] = NAN;
+    }
+  }
+  npyrng::Pcg64 g{st0, st1, st2, st3};
+  const double *__restrict__ rec = recs + (K >= 2 ? rec0 : 0) * 8;
+  bool more = K >= 2;                       // this lane still has replicates to draw
+  int rl = 0, kl = 0;                       // its replicate and its bin
+  double M1 = 0.0, M2 = 0.0;
+  int32_t dn = n;
+  bool live = true;
+  double2 c01 = *(const double2 *)(rec), c23 = *(const double2 *)(rec + 2);
+  double c_b = rec[4];
+  int64_t steps = 0;
+  for (;;) {
+#ifdef BOOT_FREE_SYNC    // experiment: the lanes meet at the end of every replicate, as in k_boot1d_replay (isolates the cost of the record layout)
+    const bool act = more && kl < K;
+    const uint64_t act_mask = __ballot(act);
+    if (act_mask == 0) {
+      if (more) {
+        double mean = M1 / nobs;
+        double var = M2 / nobs - mean * mean;
+        if (mean_only) {
+          mean = mean + 1;
+          var = 10.0;
+        }
+        om[rl] = mean;
+        ov[rl] = var;
+        rl++;
+        kl = 0;
+        M1 = 0.0;
+        M2 = 0.0;
+        dn = n;
+        live = true;
+        more = rl < num_boot;
+      }
+      if (__ballot(more) == 0) break;
+      continue;
+    }
+#else
+    const bool act = more;
+    const uint64_t act_mask = __ballot(more);
+    if (act_mask == 0) break;
+#endif
+    steps++;
+    const int cap = (BOOT_BTPE_CAP > 0 && __popcll(act_mask) > BOOT_TAIL_LANES) ? BOOT_BTPE_CAP : 0;
+    const int kn = kl + 1 < K ? kl + 1 : 0;
+    const double *nx = rec + (int64_t)kn * 8;
+    double2 n01 = *(const double2 *)(nx), n23 = *(const double2 *)(nx + 2);
+    double n_b = nx[4];
+    if (act) {
+      const double c_pk = c01.x, c_lq = c01.y, c_v = c23.x, c_a = c23.y;
+      int32_t w;
+      bool pending = false;
+      if (kl < K - 1) {
+        w = 0;
+        if (live) {
+          if constexpr (FAST) w = npyrng::binomial_pre_capped<int32_t>(g, c_pk, c_lq, dn, cap, pending);
+          else w = npyrng::binomial_pre<int32_t, false>(g, c_pk, c_lq, dn);
+          if (!pending) {
+            dn -= w;
+            if (dn <= 0) live = false;
+          }
+        }
+      } else {
+        w = dn > 0 ? dn : 0;
+      }
+      if (!pending) {
+        if (w_dump) w_dump[((int64_t)slot * kmax_dump + kl) * num_boot + rl] = (int32_t)w;
+        if (w != 0) {
+          double wd = (double)w;
+          M1 += (c_v * wd) * c_a;
+          M2 += ((c_v * c_v) * wd) * c_b - ((omq * c_v) * wd) * c_b;
+        }
+        kl++;
+        c01 = n01; c23 = n23; c_b = n_b;
+#ifndef BOOT_FREE_SYNC
+        if (kl == K) {                       // the replicate is complete (the operands just taken over are bin 0's again)
+          double mean = M1 / nobs;
+          double var = M2 / nobs - mean * mean;
+          if (mean_only) {  // estimator._mean_only_1p (estimator.py:188-204): [mean + 1, 10]
+            mean = mean + 1;
+            var = 10.0;
+          }
+#ifdef BOOT_FREE_ABLATE_STORES   // timing experiment (WRONG results): one replicate in 16 is stored
+          if ((rl & 15) == 15) {
+            om[rl] = mean;
+            ov[rl] = var;
+          }
+#elif defined(BOOT_FREE_ABLATE_DIV)   // timing experiment (WRONG results): no division in the replicate's epilogue
+          om[rl] = M1;
+          ov[rl] = M2;
+#else
+          om[rl] = mean;
+          ov[rl] = var;
+#endif
+          rl++;
+          kl = 0;
+          M1 = 0.0;
+          M2 = 0.0;
+          dn = n;
+          live = true;
+          more = rl < num_boot;
+        }
+#endif
+      }
+    }
+  }
+  if (wave_clock && lane == 0) {  // profiling hook (mm_debug_wave_clock): when this wave ran, how many bin steps it made
+    wave_clock[tile * 4 + 0] = t_start;
+    wave_clock[tile * 4 + 1] = (int64_t)wall_clock64();
+    wave_clock[tile * 4 + 2] = steps;
+    wave_clock[tile * 4 + 3] = (int64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 2D replay: same multinomial chain over the (x_i, x_j, sf_bin) bins of a gene pair; per replicate the
 // covariance and the two variances (bootstrap.py:141-155, estimator.py:214-218, :171-174) are folded
 // into the correlation exactly as estimator._corr_from_cov does (:281-292: 5.0 sentinel where a variance
@@ -1012,6 +1173,31 @@ int mm_boot1d_replay(const double *d_pk, const double *d_lq, const double *d_v, 
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
                      pcg_state[3], num_boot, mean_only, ld, d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock, ca, d_stream,
                      stream_len, d_stream_overflow);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_boot1d_free(const double *d_recs, const int64_t *d_slot_rec, int64_t n_tiles, const int32_t *d_slot_K, const double *d_slot_nobs,
+                   const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4], int32_t num_boot, int32_t mean_only,
+                   int64_t ld, double *d_out_mean, double *d_out_var, int32_t *d_w_dump, int32_t kmax_dump, const mm_chain_tiles *chains,
+                   void *stream) {
+  MM_ARG(d_recs && d_slot_rec && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
+  ChainArgs ca{};
+  if (chains) {
+    MM_ARG(chains->d_tile_chain && chains->d_ops && chains->d_ch_base && chains->d_ch_K && chains->d_ch_nobs && chains->d_ch_omq &&
+           chains->d_ch_row && chains->d_jump);
+    ca = ChainArgs{chains->d_ops, chains->d_ch_base, chains->d_ch_K, chains->d_ch_nobs, chains->d_ch_omq, chains->d_ch_row, chains->d_jump,
+                   chains->d_tile_chain, chains->d_w_dump, chains->kmax_dump, 0};
+  }
+  MM_ARG(d_out_mean && d_out_var && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_tiles == 0) return MM_OK;
+  MM_ARG(n_tiles < 2147483647LL);
+  const bool three = n_tiles > 2048;       // the register budgets of mm_boot1d_replay: three waves per SIMD beyond 2,048 tiles
+  auto kern = three ? (g_exact_arith ? k_boot1d_free<3, false> : k_boot1d_free<3, true>)
+                    : (g_exact_arith ? k_boot1d_free<BOOT_MIN_WAVES, false> : k_boot1d_free<BOOT_MIN_WAVES, true>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_recs, d_slot_rec, n_tiles, d_slot_K,
+                     d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2], pcg_state[3], num_boot, mean_only, ld,
+                     d_out_mean, d_out_var, d_w_dump, kmax_dump, g_wave_clock, ca);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -474,6 +474,12 @@ CHAIN_ALL_MAX = int(os.environ.get('MM_CHAIN_ALL_MAX', '8192'))
 # own pace, 64 chains of similar length per wave; chains with >= ASYNC_CHAIN_MIN_K bins go one per wave to mm_boot1d_chain);
 # "lockstep" = round 1-2's tile kernel (mm_boot1d_replay with the cost-model packing below; kept for A/B runs and the 2D path).
 TILE_MODE = os.environ.get('MM_TILE_MODE', 'lockstep')
+# Tiles whose lanes also run free ACROSS replicates (mm_boot1d_free: per-chain operand records instead of shared rows).  OFF, measured at
+# C3: 3.57 s against 2.99 s.  A lane no longer waits for the slowest lane of its replicate (1.13 bin steps per nominal step instead of
+# 1.23) -- but those waits were cheap: the last steps of a replicate run with few lanes left and cost accordingly (3.21 us per step made on
+# average against 4.12 us for a step of 64 busy lanes), so the launch pays for lane-steps either way; the records alone cost 3 %
+# (3.09 s with the lanes meeting at the end of each replicate), the per-lane replicate epilogue 4 %.  Bit-identical, kept as a tested option.
+TILE_FREE = os.environ.get('MM_TILE_FREE', '0') != '0'
 ASYNC_CHAIN_MIN_K = int(os.environ.get('MM_ASYNC_CHAIN_MIN_K', '160'))
 ASYNC_LANES = int(os.environ.get('MM_ASYNC_LANES', '64'))      # chains per wave of the async kernel (the other lanes idle)
 CHAIN_CLOCK_OFF = 1 << 18   # int64 offset of the chain kernel's records in the mm_debug_wave_clock buffer (tools/)
@@ -651,9 +657,9 @@ class Bootstrap1D:
         K = int(self.K[p])
         if self.async_index[p] >= 0:
             return host(self.w_dump_async[int(self.async_slot[self.async_index[p]]), :K, :])
-        if self.pair_slot[p] & CHAIN_SLOT:
+        if self.chain_index[p] >= 0:
             return host(self.w_dump_chain[int(self.chain_index[p]), :K, :])
-        return host(self.w_dump[int(self.pair_slot[p]), :K, :])
+        return host(self.w_dump[int(self.tile_slot[p]), :K, :])
 
     def alloc_outputs(self, true_mean_log, true_rv_log):
         """ym/yv [n_pairs][B+1] = NaN, column 0 = log true mean / log true residual variance (hypothesis_test.py:174)."""
@@ -722,7 +728,10 @@ class Bootstrap1D:
         self.draws_per_replicate = int(np.maximum(self.K[order_all] - 1, 0).sum())
         # one allocation: five [rows][64] operand planes of the tiles, then the chains' 8-double records
         plane = max(1, rows) * 64
-        rec_pairs = np.concatenate([chain_pairs, async_pairs])      # chains whose operands are 8-double records
+        use_free = TILE_FREE and not fast and not use_async and not REPLAY_RING and not STREAM_TABLE and n_tiles > 0 and len(order) > 0
+        if use_free:
+            plane = 64                                              # no operand rows: every chain of the launch reads records
+        rec_pairs = np.concatenate([chain_pairs, async_pairs, order if use_free else order[:0]])      # chains whose operands are 8-double records
         rec_K = self.K[rec_pairs].astype(np.int64)
         rec_base = np.concatenate([[0], np.cumsum(rec_K)]).astype(np.int64)
         ch_K, ch_base = rec_K[:n_chain], rec_base[:n_chain + 1]
@@ -734,6 +743,12 @@ class Bootstrap1D:
         self.async_index = np.full(self.n_pairs, -1, dtype=np.int64)
         self.async_index[async_pairs] = np.arange(n_async)
         self.chain_pairs, self.async_pairs = chain_pairs, async_pairs
+        self.tile_slot = np.full(self.n_pairs, -1, dtype=np.int64)          # (tile, lane) slot of the chains that run as lanes of a tile
+        self.tile_slot[order] = slot_of
+        slot_rec = None
+        if use_free:
+            slot_rec = np.full(n_tiles * 64, -1, dtype=np.int64)
+            slot_rec[slot_of] = rec_base[n_chain + n_async:-1]
         d_pair_slot, d_tile_ptr = dev(pair_slot), dev(tile_ptr)
         status = zeros((1,), torch.int32)
         d_r1, d_r0 = dev(np.asarray(r1, dtype=np.float64)), dev(np.asarray(r0, dtype=np.float64))
@@ -804,6 +819,12 @@ class Bootstrap1D:
         if n_tiles and fast:
             _lib.call("mm_boot1d_fast", *[P(o) for o in ops], P(d_tile_ptr), n_tiles * 64, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       int(fill_seed) & ((1 << 64) - 1), B, int(mean_only), ld, P(self.ym), P(self.yv), s)
+        elif n_tiles and use_free:
+            tab_over = None
+            d_slot_rec = dev(slot_rec)
+            _lib.call("mm_boot1d_free", c_void_p(self._opsbuf.data_ptr() + 5 * plane * 8), P(d_slot_rec), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq),
+                      P(d_slot_pair), pcg64_state(pcg_seed), B, int(mean_only), ld, P(self.ym), P(self.yv), P(self.w_dump), kmax_dump,
+                      ctypes.byref(chain_tiles) if chain_tiles is not None else None, s)
         elif n_tiles:
             _lib.call("mm_debug_replay_ring", 1 if REPLAY_RING else 0)
             _lib.call("mm_debug_replay_rows_mod", int(os.environ.get('MM_DEBUG_ROWS_MOD', '0')))      # timing experiments only

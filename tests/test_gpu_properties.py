@@ -171,11 +171,12 @@ def test_replay_is_independent_of_the_packing(big, monkeypatch):
     np.testing.assert_array_equal(out[0][2], out[1][2])
 
 
-def test_three_replay_kernels_agree_bit_for_bit(big, monkeypatch):
+def test_four_replay_kernels_agree_bit_for_bit(big, monkeypatch):
     """The same chains through (a) the lane-asynchronous tile kernel (mm_boot1d_async: every lane at its own pace, the draw as a
     resumable state machine), (b) the one-wave-per-chain kernel (mm_boot1d_chain: wave-uniform samplers fed by lane-parallel PCG64
-    batches) and (c) the lock-step tile kernel of rounds 1-2 (mm_boot1d_replay): integer weights and replicate moments
-    bit-identical."""
+    batches), (c) the lock-step tile kernel (mm_boot1d_replay: one BTPE attempt per bin step, the lanes meet at the end of the replicate)
+    and (d) the tile kernel whose lanes run free across replicates on per-chain operand records (mm_boot1d_free): integer weights and
+    replicate moments bit-identical."""
     engine, torch, csr, gid, blocks, sf = big
     S, sumx, maxx = blocks.moments(1.0 / sf)
     rng = np.random.default_rng(33)
@@ -186,8 +187,9 @@ def test_three_replay_kernels_agree_bit_for_bit(big, monkeypatch):
     sf_table = np.linspace(0.4, 2.5, n_bins)
     B = 150           # > 128: several 64-replicate output groups of the chain kernel and a ragged last one
     out = []
-    for mode, min_k in (("async", 0), ("lockstep", 2), ("lockstep", 0)):
-        monkeypatch.setattr(engine, "TILE_MODE", mode)
+    for mode, min_k in (("async", 0), ("lockstep", 2), ("lockstep", 0), ("free", 0)):
+        monkeypatch.setattr(engine, "TILE_MODE", "lockstep" if mode == "free" else mode)
+        monkeypatch.setattr(engine, "TILE_FREE", mode == "free")
         monkeypatch.setattr(engine, "ASYNC_CHAIN_MIN_K", 0)
         monkeypatch.setattr(engine, "CHAIN_MIN_K", min_k)
         monkeypatch.setattr(engine, "CHAIN_LONE", False)
@@ -199,7 +201,7 @@ def test_three_replay_kernels_agree_bit_for_bit(big, monkeypatch):
         bs.run(np.zeros(bs.n_pairs, bool), r[0], r[1], [0.0, 1.0, 0.0], fill_mode=1, dump_weights=True)
         n_act = int(bs.active.sum())
         assert (bs.n_async, bs.n_chain, bs.n_tiles > 0) == {("async", 0): (n_act, 0, False), ("lockstep", 2): (0, n_act, False),
-                                                            ("lockstep", 0): (0, 0, True)}[(mode, min_k)]
+                                                            ("lockstep", 0): (0, 0, True), ("free", 0): (0, 0, True)}[(mode, min_k)]
         out.append((engine.host(bs.raw_mean), engine.host(bs.raw_var), [bs.weights_of(p) for p in range(0, bs.n_pairs, 9)]))
     for other in out[1:]:
         np.testing.assert_array_equal(out[0][0], other[0])

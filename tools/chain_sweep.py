@@ -129,6 +129,10 @@ def main():
                 if sel.any():
                     print(f"     tiles of [{lo},{hi}) lanes: {sel.sum()} (bins {kmax[sel].min()}..{kmax[sel].max()}): us per (nominal) step median "
                           f"{np.median(dur[sel] / (kmax[sel] * B)) * 1e6:.2f}; wave s median {np.median(dur[sel]):.3f} max {dur[sel].max():.3f}", flush=True)
+            if engine.TILE_FREE:
+                made = wt[real, 2].astype(np.float64)
+                print(f"     free-running tiles: bin steps made / nominal, median {np.median(made / (kmax * B)):.3f} (wide tiles {np.median((made / (kmax * B))[ln >= 48]):.3f}); "
+                      f"us per step MADE, wide tiles {np.median((dur / made)[ln >= 48]) * 1e6:.2f}", flush=True)
             top = np.argsort(-dur)[:6]
             print("     longest tiles (s, lanes, bins): " + ", ".join(f"({dur[i]:.3f}, {ln[i]}, {kmax[i]})" for i in top), flush=True)
 
