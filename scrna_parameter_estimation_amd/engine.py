@@ -485,7 +485,7 @@ ASYNC_LANES = int(os.environ.get('MM_ASYNC_LANES', '64'))      # chains per wave
 CHAIN_CLOCK_OFF = 1 << 18   # int64 offset of the chain kernel's records in the mm_debug_wave_clock buffer (tools/)
 
 PAIR_SLOTS = 1024      # SIMDs: tiles t and t + PAIR_SLOTS share one
-PAIR_TILES = True      # tools only: False = plain longest-first dispatch order
+PAIR_TILES = os.environ.get('MM_PAIR_TILES', '1') != '0'      # tools only: False = plain longest-first dispatch order
 
 
 def pair_tiles(slot_of, n_tiles, K_of, cost=None):
