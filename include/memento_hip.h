@@ -386,6 +386,15 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
                      const double *d_slot_nobs, const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4],
                      int32_t num_boot, int64_t ld, double *d_out_corr, void *stream);
 
+/* The same replay with per-chain operand RECORDS instead of shared rows: slot s = 64 * tile + lane runs the chain whose 8-double records
+ * (mm_bins_order2d for pairs given as d_pair_slot[q] = MM_CHAIN_SLOT | first record: pk, lq, x_i, x_j, 1/sf, 1/sf^2, two spare) are
+ * [d_slot_rec[s], d_slot_rec[s] + d_slot_K[s]) of d_recs; d_slot_rec[s] < 0 = unused lane.  A lane then reads memory of its own whatever
+ * bin it is on, so a BTPE draw can make one attempt per bin step and retry in the next (as mm_boot1d_replay does).  Same draws and
+ * replicate correlations as mm_boot2d_replay, bit for bit.   memento/bootstrap.py:119-157, estimator.py:273-292 */
+int mm_boot2d_replay_rec(const double *d_recs, const int64_t *d_slot_rec, int64_t n_tiles, const int32_t *d_slot_K,
+                         const double *d_slot_nobs, const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4],
+                         int32_t num_boot, int64_t ld, double *d_out_corr, void *stream);
+
 /* ---- synthetic data generator (replaces memento/simulate.py:52-89 and :91-115) ----
  * Counter-based: transcriptome count z[cell][gene] ~ NB(mean[gene], size theta[gene]) is a pure function of (seed_z, cell, gene),
  * so nothing dense is ever stored.  One launch per pass, selected by `mode`:

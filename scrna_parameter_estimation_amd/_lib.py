@@ -94,6 +94,8 @@ _SIGS = {
     "mm_bins_order2d": ([c_void_p] * 6 + [c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 15, ctypes.c_int),
     "mm_boot2d_replay": ([c_void_p] * 7 + [c_int64] + [c_void_p] * 4 + [ctypes.POINTER(c_uint64), c_int32, c_int64, c_void_p, c_void_p],
                          ctypes.c_int),
+    "mm_boot2d_replay_rec": ([c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_uint64), c_int32, c_int64,
+                             c_void_p, c_void_p], ctypes.c_int),
     "mm_simulate": ([c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_uint64, c_uint64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "mm_std_normal": ([c_uint64, c_int64, c_void_p, c_void_p], ctypes.c_int),

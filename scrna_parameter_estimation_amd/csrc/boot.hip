@@ -1014,7 +1014,10 @@ __global__ __launch_bounds__(256, MINW) void k_boot1d_free(const double *__restr
 #ifndef BOOT2D_BTPE_CAP
 #define BOOT2D_BTPE_CAP 0
 #endif
-template <int MINW, bool FAST>
+#ifndef BOOT2D_REC_BTPE_CAP
+#define BOOT2D_REC_BTPE_CAP 1    // attempts per bin step when the chains read their own operand records (REC): no shared rows to scatter
+#endif
+template <int MINW, bool FAST, bool REC>
 __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__restrict__ pk_, const double *__restrict__ lq_,
                                                        const double *__restrict__ v1_, const double *__restrict__ v2_,
                                                        const double *__restrict__ a, const double *__restrict__ b,
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
                                                        const int32_t *__restrict__ slot_K, const double *__restrict__ slot_nobs,
                                                        const double *__restrict__ slot_omq, const int64_t *__restrict__ slot_row,
                                                        uint64_t st0, uint64_t st1, uint64_t st2, uint64_t st3, int32_t num_boot,
-                                                       int64_t ld, double *__restrict__ out_corr) {
+                                                       int64_t ld, double *__restrict__ out_corr, const int64_t *__restrict__ slot_rec) {
   int lane = mm_lane();
   int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (tile >= n_tiles) return;
@@ -1031,8 +1034,9 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
   int K = slot_K[slot];
   int64_t row = slot_row[slot];
   if (K <= 0 || row < 0) K = 0;
-  int64_t row0 = tile_ptr[tile];
-  int kmax = (int)(tile_ptr[tile + 1] - row0);
+  // REC: pk_ is the record buffer (8 doubles per bin: pk, lq, x_i, x_j, 1/sf, 1/sf^2, mm_bins_order2d with MM_CHAIN_SLOT pairs) and the
+  // lane's chain starts at record slot_rec[slot]; otherwise six [row][64] planes, the tile's rows from tile_ptr[tile]
+  int64_t row0 = REC ? 0 : tile_ptr[tile];
   double nobs = slot_nobs[slot];
   double omq = slot_omq[slot];
   int32_t n = (int32_t)nobs;
@@ -1042,7 +1046,19 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
   // operands of the NEXT bin step are loaded while the current one computes (as in k_boot1d_replay): the longest pair runs
   // alone in its wave and is the critical path of the launch, so an exposed L2 round trip per step is paid in full there
   const int64_t obase = row0 * 64 + lane;
-  double c_pk = pk_[obase], c_lq = lq_[obase], c_x1 = v1_[obase], c_x2 = v2_[obase], c_a = a[obase], c_b = b[obase];
+  const double *__restrict__ rec = pk_;
+  if constexpr (REC) {
+    int64_t r0 = slot_rec[slot];
+    if (r0 < 0) K = 0;
+    rec = pk_ + (K >= 1 ? r0 : 0) * 8;
+  }
+  double c_pk, c_lq, c_x1, c_x2, c_a, c_b;
+  if constexpr (REC) {
+    double2 t0 = *(const double2 *)(rec), t1 = *(const double2 *)(rec + 2), t2 = *(const double2 *)(rec + 4);
+    c_pk = t0.x; c_lq = t0.y; c_x1 = t1.x; c_x2 = t1.y; c_a = t2.x; c_b = t2.y;
+  } else {
+    c_pk = pk_[obase]; c_lq = lq_[obase]; c_x1 = v1_[obase]; c_x2 = v2_[obase]; c_a = a[obase]; c_b = b[obase];
+  }
   for (int r = 0; r < num_boot; r++) {
     double A1 = 0.0, A2 = 0.0, MX = 0.0, Q1 = 0.0, Q2 = 0.0;
     int32_t dn = n;
@@ -1056,10 +1072,18 @@ __global__ __launch_bounds__(256, MINW) void k_boot2d_replay(const double *__res
       const bool act = run && kl < K;
       const uint64_t act_mask = __ballot(act);
       if (act_mask == 0) break;
-      const int cap = (BOOT2D_BTPE_CAP > 0 && __popcll(act_mask) > BOOT_TAIL_LANES) ? BOOT2D_BTPE_CAP : 0;
+      constexpr int CAP2D = REC ? BOOT2D_REC_BTPE_CAP : BOOT2D_BTPE_CAP;
+      const int cap = (CAP2D > 0 && __popcll(act_mask) > BOOT_TAIL_LANES) ? CAP2D : 0;
       int kn = kl + 1 < K ? kl + 1 : 0;
-      int64_t on = obase + (int64_t)kn * 64;
-      double n_pk = pk_[on], n_lq = lq_[on], n_x1 = v1_[on], n_x2 = v2_[on], n_a = a[on], n_b = b[on];
+      double n_pk, n_lq, n_x1, n_x2, n_a, n_b;
+      if constexpr (REC) {
+        const double *nx = rec + (int64_t)kn * 8;
+        double2 t0 = *(const double2 *)(nx), t1 = *(const double2 *)(nx + 2), t2 = *(const double2 *)(nx + 4);
+        n_pk = t0.x; n_lq = t0.y; n_x1 = t1.x; n_x2 = t1.y; n_a = t2.x; n_b = t2.y;
+      } else {
+        int64_t on = obase + (int64_t)kn * 64;
+        n_pk = pk_[on]; n_lq = lq_[on]; n_x1 = v1_[on]; n_x2 = v2_[on]; n_a = a[on]; n_b = b[on];
+      }
       bool adv = false;
       if (act) {
         int32_t w;
@@ -1261,11 +1285,27 @@ int mm_boot2d_replay(const double *d_pk, const double *d_lq, const double *d_v1,
   MM_ARG(d_pk && d_lq && d_v1 && d_v2 && d_a && d_b && d_tile_ptr && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
   MM_ARG(d_out_corr && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
   if (n_tiles == 0) return MM_OK;
-  auto kern = n_tiles > 2048 ? (g_exact_arith ? k_boot2d_replay<3, false> : k_boot2d_replay<3, true>)
-                             : (g_exact_arith ? k_boot2d_replay<BOOT_MIN_WAVES, false> : k_boot2d_replay<BOOT_MIN_WAVES, true>);
+  auto kern = n_tiles > 2048 ? (g_exact_arith ? k_boot2d_replay<3, false, false> : k_boot2d_replay<3, true, false>)
+                             : (g_exact_arith ? k_boot2d_replay<BOOT_MIN_WAVES, false, false> : k_boot2d_replay<BOOT_MIN_WAVES, true, false>);
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pk, d_lq, d_v1, d_v2, d_a, d_b,
                      d_tile_ptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1], pcg_state[2],
-                     pcg_state[3], num_boot, ld, d_out_corr);
+                     pcg_state[3], num_boot, ld, d_out_corr, (const int64_t *)nullptr);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_boot2d_replay_rec(const double *d_recs, const int64_t *d_slot_rec, int64_t n_tiles, const int32_t *d_slot_K,
+                         const double *d_slot_nobs, const double *d_slot_omq, const int64_t *d_slot_row, const uint64_t pcg_state[4],
+                         int32_t num_boot, int64_t ld, double *d_out_corr, void *stream) {
+  MM_ARG(d_recs && d_slot_rec && d_slot_K && d_slot_nobs && d_slot_omq && d_slot_row && pcg_state);
+  MM_ARG(d_out_corr && n_tiles >= 0 && num_boot > 0 && ld >= (int64_t)num_boot + 1);
+  if (n_tiles == 0) return MM_OK;
+  auto kern = n_tiles > 2048 ? (g_exact_arith ? k_boot2d_replay<3, false, true> : k_boot2d_replay<3, true, true>)
+                             : (g_exact_arith ? k_boot2d_replay<BOOT_MIN_WAVES, false, true> : k_boot2d_replay<BOOT_MIN_WAVES, true, true>);
+  const double *nul = nullptr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_recs, nul, nul, nul, nul, nul,
+                     (const int64_t *)nullptr, n_tiles, d_slot_K, d_slot_nobs, d_slot_omq, d_slot_row, pcg_state[0], pcg_state[1],
+                     pcg_state[2], pcg_state[3], num_boot, ld, d_out_corr, d_slot_rec);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -323,8 +323,11 @@ __global__ __launch_bounds__(NT) void k_bins_order2d(const uint32_t *__restrict_
       __syncthreads();
     }
   }
+  // slot = tile*64 + lane of the 64-wide tile layout, or MM_CHAIN_SLOT | first record: the chain's operands then go, bin by bin, into
+  // 8-double records at o_pk + 8*(record + k): pk, lq, x_i, x_j, 1/sf, 1/sf^2 (mm_boot2d_replay_rec)
+  const bool recs = (slot & MM_CHAIN_SLOT) != 0;
   int64_t tile = slot >> 6, ln = slot & 63;
-  int64_t row0 = tile_ptr[tile];
+  int64_t row0 = recs ? (slot & (MM_CHAIN_SLOT - 1)) : tile_ptr[tile];
   double N = grp_ncells[grp];
   bool tie = false;
   for (int k = tid; k + 1 < K; k += NT)
@@ -342,6 +345,16 @@ __global__ __launch_bounds__(NT) void k_bins_order2d(const uint32_t *__restrict_
     uint32_t bin = (uint32_t)(pay[k] >> 40), xi = (uint32_t)((pay[k] >> 20) & 0xFFFFFu), xj = (uint32_t)(pay[k] & 0xFFFFFu);
     double sf = sf_table[bin];
     double pk = ((double)mult[k] / N) / code[k];
+    if (recs) {
+      double *rec = o_pk + (row0 + k) * 8;
+      rec[0] = pk;
+      rec[1] = npyrng::binomial_lq(pk);
+      rec[2] = (double)xi;
+      rec[3] = (double)xj;
+      rec[4] = 1.0 / sf;
+      rec[5] = 1.0 / (sf * sf);
+      continue;
+    }
     int64_t o = (row0 + k) * 64 + ln;
     o_pk[o] = pk;
     o_lq[o] = npyrng::binomial_lq(pk);

@@ -480,6 +480,8 @@ TILE_MODE = os.environ.get('MM_TILE_MODE', 'lockstep')
 # average against 4.12 us for a step of 64 busy lanes), so the launch pays for lane-steps either way; the records alone cost 3 %
 # (3.09 s with the lanes meeting at the end of each replicate), the per-lane replicate epilogue 4 %.  Bit-identical, kept as a tested option.
 TILE_FREE = os.environ.get('MM_TILE_FREE', '0') != '0'
+# 2D replay on per-chain operand records with one BTPE attempt per bin step (mm_boot2d_replay_rec) instead of shared rows, every attempt in its step
+BOOT2D_RECORDS = os.environ.get('MM_BOOT2D_RECORDS', '1') != '0'
 ASYNC_CHAIN_MIN_K = int(os.environ.get('MM_ASYNC_CHAIN_MIN_K', '160'))
 ASYNC_LANES = int(os.environ.get('MM_ASYNC_LANES', '64'))      # chains per wave of the async kernel (the other lanes idle)
 CHAIN_CLOCK_OFF = 1 << 18   # int64 offset of the chain kernel's records in the mm_debug_wave_clock buffer (tools/)
@@ -1072,6 +1074,12 @@ class Bootstrap2D:
         with np.errstate(divide="ignore", invalid="ignore"):
             lq = np.log(1.0 - peff)
         sf = self.sf_table[bi]
+        if slot & CHAIN_SLOT:      # 8-double records (mm_boot2d_replay_rec), addressed from the start of ops[0]
+            rec = np.zeros((len(pk), 8))
+            rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5] = pk, lq, xi, xj, 1.0 / sf, 1.0 / (sf * sf)
+            r0_ = (slot & (CHAIN_SLOT - 1)) * 8
+            ops[0][r0_:r0_ + rec.size] = dev(rec.reshape(-1))
+            return
         idx = dev((int(tile_ptr[slot >> 6]) + np.arange(len(pk), dtype=np.int64)) * 64 + (slot & 63))
         for arr, vals in zip(ops, (pk, lq, xi, xj, 1.0 / sf, 1.0 / (sf * sf))):
             arr[idx] = dev(vals)
@@ -1099,7 +1107,20 @@ class Bootstrap2D:
         rows = int(tile_ptr[-1])
         self.draws_per_replicate = int(np.maximum(self.K[order] - 1, 0).sum())
         self.wave_steps_per_replicate = rows
-        ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(6)]
+        use_rec = BOOT2D_RECORDS and n_tiles > 0
+        slot_rec = None
+        if use_rec:
+            # per-chain operand records (8 doubles per bin) instead of [row][64] planes: a lane reads memory of its own wherever it is in
+            # its chain, so the kernel can let a rejected BTPE attempt retry in the next bin step (mm_boot2d_replay_rec)
+            rec_K = self.K[order].astype(np.int64)
+            rec_base = np.concatenate([[0], np.cumsum(rec_K)]).astype(np.int64)
+            ops = [empty((8 * max(1, int(rec_base[-1])),), torch.float64)] + [empty((8,), torch.float64) for _ in range(5)]
+            self.tile_slot = pair_slot.copy()
+            pair_slot[order] = CHAIN_SLOT | rec_base[:-1]
+            slot_rec = np.full(n_tiles * 64, -1, dtype=np.int64)
+            slot_rec[slot_of] = rec_base[:-1]
+        else:
+            ops = [empty((max(1, rows) * 64,), torch.float64) for _ in range(6)]
         d_pair_slot, d_tile_ptr = dev(pair_slot), dev(tile_ptr)
         status = zeros((1,), torch.int32)
         d_ra, d_rb, d_r0 = dev(np.asarray(r1a, np.float64)), dev(np.asarray(r1b, np.float64)), dev(np.asarray(r0, np.float64))
@@ -1122,7 +1143,11 @@ class Bootstrap2D:
         self.yc = torch.full((max(1, self.n_q), ld), float("nan"), dtype=torch.float64, device="cuda")
         self.yc[: self.n_q, 0] = dev(np.asarray(true_corr, dtype=np.float64))
         d_slot_K, d_nobs, d_omq, d_slot_pair = dev(slot_K), dev(nobs), dev(omq), dev(slot_pair)
-        if n_tiles:
+        if n_tiles and use_rec:
+            d_slot_rec = dev(slot_rec)
+            _lib.call("mm_boot2d_replay_rec", P(ops[0]), P(d_slot_rec), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
+                      pcg64_state(pcg_seed), B, ld, P(self.yc), s)
+        elif n_tiles:
             _lib.call("mm_boot2d_replay", *[P(o) for o in ops], P(d_tile_ptr), n_tiles, P(d_slot_K), P(d_nobs), P(d_omq), P(d_slot_pair),
                       pcg64_state(pcg_seed), B, ld, P(self.yc), s)
         st = int(status.item())
