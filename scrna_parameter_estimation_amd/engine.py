@@ -44,12 +44,12 @@ _PACK_L = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36, 40, 4
 _PACK_US = (0.72, 1.42, 1.66, 1.88, 2.00, 2.08, 2.18, 2.26, 2.41, 2.49, 2.61, 2.68, 2.77, 2.86, 3.02, 3.13, 3.16, 3.17, 3.18, 3.26, 3.32, 3.60, 3.87)
 _PACK_US_2D = (0.96, 1.30, 1.52, 1.72, 1.87, 1.97, 2.09, 2.20, 2.39, 2.56, 2.74, 2.83, 2.99, 3.13, 3.32, 3.55, 3.67, 3.79, 3.90, 4.05, 4.17, 4.50, 4.81)
 PACK_COST = np.interp(np.arange(1, 65), _PACK_L, _PACK_US)
-PACK_COST_2D = np.interp(np.arange(1, 65), _PACK_L, _PACK_US_2D)
+PACK_COST_2D = np.interp(np.arange(1, 65), _PACK_L, _PACK_US_2D if os.environ.get('MM_PACK2D_COST', '2d') == '2d' else _PACK_US)   # (env: tools only)
 # (c) many-chain regime (more tiles than resident wave slots): 2 x 1024 slots; a SIMD retires ~1.46 lone-wave-seconds of tile
 # time per second (older wave 1.0 + younger ~0.46); a tile may take at most PACK_TAIL of the work-bound run time
 PACK_MAX_RESIDENT = 2048
 PACK_RATE = 1024 * 1.46
-PACK_TAIL = 0.5
+PACK_TAIL = float(os.environ.get('MM_PACK_TAIL', '0.5'))   # (env: tools only)
 PACK_FORCE = ""          # tools only (tools/pack_sweep.py): "res" / "cap" forces one of the two packings
 PACK_LAST = {}          # diagnostics of the last pack_lanes decision (tools/)
 
