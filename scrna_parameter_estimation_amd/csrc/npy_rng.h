@@ -405,12 +405,10 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
     cap_end = (int32_t)capf;
     X = inversion_steps<10, 60>(Uf, px, a_s, s);
   }
-  {
-    const float G = (NPY_INV_G0 + (n < (Int)128 ? NPY_INV_GS : 0.0f)) + NPY_INV_GA * fabsf(argf) + NPY_INV_GX * (float)X;
-    bool ok = (px - Uf > G) && (X == 0 || Uf > G) && X <= cap_end;
-    return ok ? X : -1;
-  }
-#endif
+  const float G = (NPY_INV_G0 + (n < (Int)128 ? NPY_INV_GS : 0.0f)) + NPY_INV_GA * fabsf(argf) + NPY_INV_GX * (float)X;
+  bool ok = (px - Uf > G) && (X == 0 || Uf > G) && X <= cap_end;
+  return ok ? X : -1;
+#else    // round 2's form: the bound checked in every step (kept for A/B runs)
   const int32_t cap9 = n < (Int)9 ? (int32_t)n : 9;
 #pragma unroll
   for (int it = 1; it <= 9; it++) {
@@ -441,6 +439,7 @@ NPY_HD int32_t binomial_inversion_fast(double U, Int n, double p, double lq) {
   const float G = (NPY_INV_G0 + (n < (Int)128 ? NPY_INV_GS : 0.0f)) + NPY_INV_GA * fabsf(argf) + NPY_INV_GX * (float)X;
   bool ok = (px - Uf > G) && (X == 0 || Uf > G);   // also false when the search stopped at a cap
   return ok ? X : -1;
+#endif
 }
 
 // BTPE's explicit evaluation of f(y)/f(m) against v, in fp32.  +1: v <= F (numpy breaks: accept), 0: v > F (numpy continues:
